@@ -1,0 +1,251 @@
+"""ORACLE / TEST INFRASTRUCTURE -- build-container only.  Generates tests/golden/*.npz.
+
+Runs the REFERENCE's own code (imported read-only from /root/reference under oracle/shim) on small
+seeded inputs and on the reference's shipped artefacts, and stores inputs + expected outputs as
+plain arrays.  Only arrays are committed; no reference source/bytecode travels.
+Re-run:  python oracle/gen_golden.py        (deterministic: fixed seeds, CPU, torch 2.10)
+Fixtures:
+  office_a2d_graph.npz   shipped office A->D bridged graph (x, edge_index, y, masks)  [G5 data]
+  conv_office.npz        G1: AdaptedConv(256,64) on the undirected office graph
+  conv_small_D*.npz      G1: 200-node multigraph w/ isolated nodes, D in {2,31,64,128}
+  ktgnn_office.npz       G2: KTGNN_no_complement(256,31,2,64,use_bn) eval forward, office graph
+  ktgnn_sync.npz         G2: same on the 10k-node C2 synthetic graph (row subset + sums)
+  partition_office.npz   G3: graph_partition / coalesce / to_undirected outputs
+  knn_office_a2d.npz, knn_office_a2w.npz   G4(i)+G5: shipped ckpts (v2 / mlp scorer)
+  knn_cosine_v1.npz      G4(ii): v1 cosine scorer (twitter ckpt) on seeded synthetic features
+  knn_gauss.npz          G4(iii): raw Gaussian d=128 cosine (Similar_noTrans), Ns=20k, Nt=2k
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+from bridged_gnn_amd import synth  # noqa: E402
+from bridged_gnn_amd.data import load_bridged_graph  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = ref_import.REF_ROOT
+torch.set_num_threads(8)
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}: {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def randomize_bn(module, gen):
+    """Non-trivial running stats / affine so eval-mode BN is actually exercised."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    KT, MD, BG = ref_import.import_reference()
+    import torch_geometric
+    from torch_geometric.data import Data as SData
+    from torch_geometric.utils import coalesce as s_coalesce, to_undirected as s_to_undirected
+
+    # ------------------------------------------------------------------ shipped office A->D graph
+    print("[G5] shipped office graphs")
+    d = load_bridged_graph(os.path.join(REF, "data_bridged_graph/office_amazon2dslr_bridged_graph.dat"))
+    x, ei, cm = d.x, d.edge_index, d.central_mask
+    assert bool(cm[:2817].all()) and not bool(cm[2817:].any())
+    save("office_a2d_graph.npz", x=x.numpy(), edge_index=ei.numpy().astype(np.int32), y=d.y.numpy(),
+         train_mask=d.train_mask.numpy(), val_mask=d.val_mask.numpy(), test_mask=d.test_mask.numpy(),
+         central_mask=cm.numpy())
+    ei_und = s_to_undirected(ei, num_nodes=x.shape[0])
+
+    # ------------------------------------------------------------------ G3 partition
+    print("[G3] graph_partition / coalesce / to_undirected")
+    model = KT.KTGNN_no_complement(256, 31, 2, 64, root_weight=False, use_bn=True, dim_share=256,
+                                   need_complement=False)
+    e1, e2, ecat = model.graph_partition(ei_und, cm)
+    e1d, e2d, _ = model.graph_partition(ei, cm)
+    save("partition_office.npz", ei_undirected=ei_und.numpy().astype(np.int32),
+         e1=e1.numpy().astype(np.int32), e2=e2.numpy().astype(np.int32),
+         e1_directed=e1d.numpy().astype(np.int32), e2_directed=e2d.numpy().astype(np.int32))
+
+    # ------------------------------------------------------------------ G1 AdaptedConv on office
+    print("[G1] AdaptedConv office")
+    torch.manual_seed(0)
+    conv = KT.AdaptedConv(256, 64, root_weight=False).eval()
+    with torch.no_grad():
+        # intermediate tensors by re-tracing the reference's own ops (KTGNN.py:275-299)
+        out = conv(x, ecat, e1, e2, cm)
+        xs = x
+        dd = xs[cm].mean(0, keepdim=True) - xs[~cm].mean(0, keepdim=True)
+        dd = dd.expand(xs.shape)
+        s2t = torch.tanh(conv.a_g_s2t(torch.cat((xs, dd), -1))) * dd
+        t2s = torch.tanh(conv.a_g_t2s(torch.cat((xs, dd), -1))) * dd
+        h_s2t = conv.lin_t(xs - s2t * cm.unsqueeze(-1))
+        h_t2s = conv.lin_s(xs + t2s * (~cm).unsqueeze(-1))
+        a1 = conv.a_f_t2s(torch.nn.functional.leaky_relu(h_t2s[e1[0]] + h_t2s[e1[1]], 0.1))
+        a2 = conv.a_f_s2t(torch.nn.functional.leaky_relu(h_s2t[e2[0]] + h_s2t[e2[1]], 0.1))
+        alpha = torch_geometric.utils.softmax(torch.cat((a1, a2), 0), ecat[1], num_nodes=x.shape[0])
+    save("conv_office.npz", out=out.numpy(), alpha=alpha.numpy().reshape(-1),
+         h_s2t_rows=h_s2t[::8].numpy(), h_t2s_rows=h_t2s[::8].numpy(), **sd_np(conv, "p."))
+
+    # ------------------------------------------------------------------ G1 small multigraphs
+    print("[G1] AdaptedConv small multigraphs")
+    for D in (2, 31, 64, 128):
+        gen = torch.Generator().manual_seed(100 + D)
+        n, din = 200, 48
+        ei_s, m_s = synth.random_multigraph(n, 1500, frac_src=0.45, n_isolated=7, seed=D)
+        ei_t, m_t = torch.from_numpy(ei_s), torch.from_numpy(m_s)
+        xs = torch.randn(n, din, generator=gen)
+        torch.manual_seed(D)
+        conv = KT.AdaptedConv(din, D, root_weight=False).eval()
+        mm = KT.KTGNN_no_complement(din, 2, 2, 8, dim_share=din)
+        f1, f2, fc = mm.graph_partition(ei_t, m_t)
+        with torch.no_grad():
+            o = conv(xs, fc, f1, f2, m_t)
+        save(f"conv_small_D{D}.npz", x=xs.numpy(), edge_index=ei_s.astype(np.int32), central_mask=m_s,
+             out=o.numpy(), **sd_np(conv, "p."))
+
+    # ------------------------------------------------------------------ G2 KTGNN office
+    print("[G2] KTGNN office")
+    torch.manual_seed(0)
+    model = KT.KTGNN_no_complement(256, 31, 2, 64, root_weight=False, use_bn=True, dim_share=256,
+                                   need_complement=False)
+    randomize_bn(model, torch.Generator().manual_seed(7))
+    model.eval()
+    data = SData(x=x, edge_index=ei_und, y=d.y, central_mask=cm)
+    with torch.no_grad():
+        lb, lt, lth, _ = model(data)
+        emb = model.get_emb(data)
+    save("ktgnn_office.npz", logp_base=lb.numpy(), logp_target=lt.numpy(), logp_target_hat=lth.numpy(),
+         emb_rows=emb[::8].numpy(), **sd_np(model, "sd."))
+
+    # ------------------------------------------------------------------ G2 KTGNN on C2 synthetic
+    print("[G2] KTGNN sync-rd (C2)")
+    xs, ei_s, ys, ms = synth.sync_rd_intra(n=10000, feat=64, homophily=0.7, deg=10, k_cross=20, seed=0)
+    ei_u = s_to_undirected(torch.from_numpy(ei_s), num_nodes=10000)
+    torch.manual_seed(1)
+    model = KT.KTGNN_no_complement(64, 2, 2, 64, root_weight=False, use_bn=True, dim_share=64,
+                                   need_complement=False)
+    randomize_bn(model, torch.Generator().manual_seed(8))
+    model.eval()
+    data = SData(x=torch.from_numpy(xs), edge_index=ei_u, y=torch.from_numpy(ys),
+                 central_mask=torch.from_numpy(ms))
+    with torch.no_grad():
+        lb, lt, lth, _ = model(data)
+    rows = np.arange(0, 10000, 16)
+    save("ktgnn_sync.npz", rows=rows, logp_base=lb.numpy()[rows], logp_target=lt.numpy()[rows],
+         logp_target_hat=lth.numpy()[rows],
+         sums=np.array([lb.double().sum().item(), lt.double().sum().item(), lth.double().sum().item()]),
+         n_edges_undirected=np.int64(ei_u.shape[1]), **sd_np(model, "sd."))
+
+    # ------------------------------------------------------------------ G4(i)/G5 office kNN
+    for tag, k_cross in (("a2d", 20), ("a2w", 8)):
+        name = {"a2d": "office_amazon2dslr", "a2w": "office_amazon2webcam"}[tag]
+        print(f"[G4/G5] kNN {name}")
+        dd = load_bridged_graph(os.path.join(REF, f"data_bridged_graph/{name}_bridged_graph.dat"))
+        cmk = dd.central_mask
+        ns = int(cmk.sum())
+        assert bool(cmk[:ns].all())
+        nt = dd.x.shape[0] - ns
+        loops = lambda n: torch.arange(n).unsqueeze(0).repeat(2, 1)
+        ds = SData(x=dd.x[:ns], edge_index=loops(ns), y=dd.y[:ns].clone())
+        dt = SData(x=dd.x[ns:], edge_index=loops(nt), y=dd.y[ns:].clone(),
+                   train_mask=dd.train_mask[ns:], val_mask=dd.val_mask[ns:], test_mask=dd.test_mask[ns:])
+        # num_classes is derived from y.max() in the reference ctor (models.py:1004); the shipped
+        # target y contains -1 for unlabeled nodes, classes = 31
+        ds_ctor = SData(x=ds.x, edge_index=ds.edge_index, y=torch.clamp(ds.y, min=0))
+        ds_ctor.y[0] = 30
+        dt_ctor = SData(x=dt.x, edge_index=dt.edge_index, y=torch.clamp(dt.y, min=0))
+        dt_ctor.y[0] = 30
+        sim = MD.Adversarial_Learner_v2(ds_ctor, dt_ctor, dim_hidden=128, num_layer=2, use_norm=True,
+                                        source_clf=True, norm_mode="None", norm_scale=1.0,
+                                        sim_mode="mlp", backbone="mlp")
+        sd = torch.load(os.path.join(REF, f"ckpt/model_AdvLearner_{name}_best.ckpt"),
+                        map_location="cpu", weights_only=True)
+        sim.load_state_dict(sd, strict=True)
+        sim.eval()
+        with torch.no_grad():
+            ec, esim, eidx, pcs, pct = BG.add_topk_sim_cross_domain_edges(ds, dt, sim, k=k_cross, batch_size=100)
+            z_src = sim.source_learner.backbone(ds.x, ds.edge_index)
+            z_tar, _ = sim.target_learner.encode(dt)
+            es, esims, eidxs = BG.add_topk_sim_within_domain_edges(ds, sim, k=3, batch_size=100, domain="source")
+            et, esimt, eidxt = BG.add_topk_sim_within_domain_edges(dt, sim, k=3, batch_size=100, domain="target")
+        simnet = {"sim." + k[len("source_learner.sim_net."):]: v.numpy() for k, v in sd.items()
+                  if k.startswith("source_learner.sim_net.")}
+        save(f"knn_office_{tag}.npz", z_src=z_src.numpy(), z_tar=z_tar.numpy(), k_cross=np.int64(k_cross),
+             cross_edge_index=ec.numpy().astype(np.int32), cross_e_sim=esim.numpy(),
+             cross_idx=eidx.numpy().astype(np.int32),
+             pred_clf_src=pcs.argmax(1).numpy().astype(np.int16), pred_clf_tar=pct.argmax(1).numpy().astype(np.int16),
+             probs_clf_src_rows=pcs[::16].numpy(), probs_clf_tar_rows=pct[::16].numpy(),
+             within_src_edge_index=es.numpy().astype(np.int32), within_src_e_sim=esims.numpy(),
+             within_src_idx=eidxs.numpy().astype(np.int32),
+             within_tar_edge_index=et.numpy().astype(np.int32), within_tar_e_sim=esimt.numpy(),
+             within_tar_idx=eidxt.numpy().astype(np.int32),
+             shipped_edge_index=dd.edge_index.numpy().astype(np.int32), n_src=np.int64(ns),
+             y=dd.y.numpy().astype(np.int16), **simnet)
+
+    # ------------------------------------------------------------------ G4(ii) v1 cosine scorer
+    print("[G4] v1 cosine scorer (twitter ckpt, synthetic features)")
+    gen = torch.Generator().manual_seed(11)
+    ns = nt = 2000
+    F_in = 300
+    loops = lambda n: torch.arange(n).unsqueeze(0).repeat(2, 1)
+    ds = SData(x=torch.randn(ns, F_in, generator=gen) * 0.5, edge_index=loops(ns),
+               y=torch.randint(0, 2, (ns,), generator=gen))
+    dt = SData(x=torch.randn(nt, F_in, generator=gen) * 0.5 + 0.1, edge_index=loops(nt),
+               y=torch.randint(0, 2, (nt,), generator=gen))
+    sim = MD.Adversarial_Learner(ds, dt, dim_hidden=64, num_layer=2, source_clf=True, norm_mode="None", norm_scale=1.0)
+    sd = torch.load(os.path.join(REF, "ckpt/model_AdvLearner_twitter_unrelational_best.ckpt"),
+                    map_location="cpu", weights_only=True)
+    sim.load_state_dict(sd, strict=True)
+    sim.eval()
+    with torch.no_grad():
+        ec, esim, eidx, pcs, pct = BG.add_topk_sim_cross_domain_edges(ds, dt, sim, k=20, batch_size=100)
+        z_src = sim.source_learner.backbone(ds.x, ds.edge_index)
+        z_tar, _ = sim.target_learner.encode(dt)
+        sn = sim.source_learner.sim_net
+        u_s, u_t = sn.lin_self(z_src), sn.lin_self(z_tar)
+        q_src, q_tar = u_s + sn.biasatt(u_s), u_t + sn.biasatt(u_t)
+    simnet = {"sim." + k[len("source_learner.sim_net."):]: v.numpy() for k, v in sd.items()
+              if k.startswith("source_learner.sim_net.")}
+    save("knn_cosine_v1.npz", z_src=z_src.numpy(), z_tar=z_tar.numpy(), q_src=q_src.numpy(), q_tar=q_tar.numpy(),
+         cross_edge_index=ec.numpy().astype(np.int32), cross_e_sim=esim.numpy(),
+         cross_idx=eidx.numpy().astype(np.int32), **simnet)
+
+    # ------------------------------------------------------------------ G4(iii) raw Gaussian cosine
+    print("[G4] raw Gaussian cosine via Similar_noTrans")
+    ns, nt, dimq, k = 20000, 2000, 128, 20
+    q_src = torch.from_numpy(synth.gaussian_embeddings(ns, dimq, seed=21))
+    q_tar = torch.from_numpy(synth.gaussian_embeddings(nt, dimq, seed=22))
+    snt = MD.Similar_noTrans(dimq, 2, use_clf=False).eval()
+    all_src = torch.arange(ns).unsqueeze(-1)
+    vals, idxs = [], []
+    with torch.no_grad():
+        for s in range(0, nt, 50):
+            bt = torch.arange(s, min(s + 50, nt)).unsqueeze(-1)
+            pairs = MD.pair_enumeration(all_src, bt).transpose(0, 1)          # main_bridged_graph.py:49
+            p = snt.similarity_cross_domain(q_src, q_tar, pairs[0], pairs[1])  # models.py:185-189
+            tk = p.view(-1, ns).topk(k=k, dim=1, largest=True, sorted=False)   # main_bridged_graph.py:59-60
+            vals.append(tk.values)
+            idxs.append(tk.indices)
+    vals, idxs = torch.cat(vals), torch.cat(idxs)
+    save("knn_gauss.npz", ns=np.int64(ns), nt=np.int64(nt), d=np.int64(dimq), k=np.int64(k),
+         seed_src=np.int64(21), seed_tar=np.int64(22), e_sim=vals.numpy(), idx=idxs.numpy().astype(np.int32))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
