@@ -1,0 +1,74 @@
+"""ctypes binding of `csrc/libbgnn_hip.so` (C ABI declared in include/bgnn.h).
+
+There is NO fallback: if the library is absent or an operand is not a CUDA(HIP) tensor the call
+raises.  PyTorch only supplies device memory and the current stream."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libbgnn_hip.so")
+_lib = None
+
+_P, _I64, _I32, _F32, _SZ, _INT = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t, C.c_int
+
+# name -> (restype, argtypes); mirrors include/bgnn.h one to one
+SIGNATURES = {
+    "bgnn_version": (_INT, []),
+    "bgnn_error_string": (C.c_char_p, [_INT]),
+    "bgnn_csr_workspace_bytes": (_SZ, [_I64, _I64]),
+    "bgnn_build_dst_csr": (_INT, [_P, _I64, _I64, _INT, _P, _P, _P, _P, _P, _SZ, _P]),
+    "bgnn_domain_sums_f64": (_INT, [_P, _I64, _I32, _I64, _P, _P, _P]),
+    "bgnn_domain_delta_f32": (_INT, [_P, _I32, _P, _P]),
+    "bgnn_adaptedconv_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32,
+                                               _P, _P, _I64, _P, _P]),
+    "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _F32,
+                                               _P, _I64, _P, _P, _P, _INT, _P]),
+    "bgnn_l2_normalize_rows_f32": (_INT, [_P, _I64, _I32, _F32, _P, _P]),
+    "bgnn_topk_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
+    "bgnn_cosine_topk_f32": (_INT, [_P, _P, _I64, _I64, _I32, _I32, _INT, _P, _P, _P, _P, _SZ, _P]),
+    "bgnn_mlp_pair_topk_f32": (_INT, [_P, _P, _P, _P, _P, _F32, _I64, _I64, _I32, _I32, _INT, _P, _P, _P,
+                                       _P, _SZ, _P]),
+    "bgnn_topk_edges_i64": (_INT, [_P, _I64, _I32, _I64, _I64, _P, _P]),
+    "bgnn_coalesce_workspace_bytes": (_SZ, [_I64]),
+    "bgnn_coalesce_i64": (_INT, [_P, _I64, _I64, _P, _P, _SZ, _P]),
+}
+
+
+def lib():
+    """Load libbgnn_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C bridged_gnn_amd/csrc`).  bridged_gnn_amd has no CPU fallback.")
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().bgnn_error_string(int(rc))
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else rc} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL); refuses host tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("bridged_gnn_amd ops need CUDA(HIP) tensors; there is no CPU path "
+                           f"(got a {t.device} tensor)")
+    if not t.is_contiguous():
+        raise RuntimeError("bridged_gnn_amd ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

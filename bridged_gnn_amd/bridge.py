@@ -1,0 +1,232 @@
+"""Bridged-graph (kNN) construction on MI355X -- host-side mirror of the reference's step-1 hot
+functions (Bridged-GNN/main_bridged_graph.py:33-120, :163-193) over the HIP library.
+
+The reference enumerates every (candidate, query) index pair per batch, re-runs both encoders and
+pushes [Ns*B, 128] gathers through the scorer.  Here the per-node part of each
+scorer is evaluated once per node and the per-pair part is a streaming top-k kernel:
+  cosine (`Similar`, `Similar_v2(mode='cosine')`, `Similar_noTrans`; models/models.py:124-130,
+          :945-948, :185-189):  q = u + biasatt(u), u = lin_self(z)  per node, then
+          normalise rows and run `bgnn_cosine_topk_f32` (fp32 MFMA);
+  mlp    (`Similar_v2(mode='mlp')`, :949-951): eval-mode BN/Linear are affine, so
+          W1.bn1([z_s||z_t]) = A[s] + B[t]; `bgnn_mlp_pair_topk_f32` evaluates
+          w2.relu(bn2(A[s]+B[t])) + b2 per pair.
+`batch_size`/`epsilon` are accepted for signature compatibility (epsilon is unused by the reference
+too, main_bridged_graph.py:33); batching is internal to the kernels.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .data import Data
+
+__all__ = ["BridgeScorer", "add_topk_sim_cross_domain_edges", "add_topk_sim_within_domain_edges",
+           "merge_graphs", "pair_enumeration"]
+
+_BN_EPS = 1e-5
+
+
+def pair_enumeration(x1, x2):
+    """models/models.py:265-282 (x2-major enumeration).  Provided for API parity / small tests only:
+    the top-k path never materialises pairs."""
+    assert x1.dim() == 2 and x2.dim() == 2, "Input dimension must be 2"
+    x1_ = x1.repeat(x2.size(0), 1)
+    x2_ = x2.repeat(1, x1.size(0)).view(-1, x1.size(1))
+    return torch.cat((x1_, x2_), dim=1)
+
+
+def _bn_affine(sd, prefix):
+    inv = sd[prefix + "weight"] / torch.sqrt(sd[prefix + "running_var"] + _BN_EPS)
+    return inv, sd[prefix + "bias"] - sd[prefix + "running_mean"] * inv
+
+
+class BridgeScorer:
+    """Eval-mode pair scorer + (v2/mlp-backbone) encoders of the reference's trained similarity
+    learner, built from its checkpoint state_dict (`Adversarial_Learner{,_v2}`,
+    models/models.py:815-844, :1110-1142; key layout in SURVEY.md 8(b)).  Weights live on `device`."""
+
+    def __init__(self, state_dict, device, norm_mode="None", norm_scale=1.0):
+        sd = {k: v.to(device=device, dtype=torch.float32) if v.is_floating_point() else v.to(device)
+              for k, v in state_dict.items()}
+        self.sd, self.device = sd, torch.device(device)
+        self.norm_mode, self.norm_scale = norm_mode, norm_scale
+        p = "source_learner.sim_net."
+        self.sim = {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+        self.version = "v2" if "source_learner.backbone.layers.0.weight" in sd else "v1"
+        if "biasatt.0.weight" in self.sim:
+            self.sim_mode = "cosine"
+        elif "lin_self.4.bias" in self.sim:
+            self.sim_mode = "mlp"
+        else:
+            self.sim_mode = "cosine_notrans"        # Similar_noTrans: q = z
+        self.use_clf = "lin_clf.weight" in self.sim
+
+    # ---- encoders (dense per-node work, run ONCE; reference re-runs them per batch :56,:100) ----
+    def _pairnorm(self, x):
+        """models/models.py:29-64"""
+        mode, scale = self.norm_mode, self.norm_scale
+        if mode == "None":
+            return x
+        col_mean = x.mean(dim=0)
+        if mode == "PN":
+            x = x - col_mean
+            return scale * x / (1e-6 + x.pow(2).sum(dim=1).mean()).sqrt()
+        if mode == "PN-SI":
+            x = x - col_mean
+            return scale * x / (1e-6 + x.pow(2).sum(dim=1, keepdim=True)).sqrt()
+        if mode == "PN-SCS":
+            return scale * x / (1e-6 + x.pow(2).sum(dim=1, keepdim=True)).sqrt() - col_mean
+        raise NotImplementedError(mode)
+
+    def _mlp_encoder(self, x, prefix):
+        """`MLP.forward` eval mode, models/models.py:880-893 (use_norm=True at every v2 call site)."""
+        sd = self.sd
+        x = F.linear(x, sd[prefix + "layers.0.weight"], sd[prefix + "layers.0.bias"])
+        x = F.relu(self._pairnorm(x))
+        return F.linear(x, sd[prefix + "layers.1.weight"], sd[prefix + "layers.1.bias"])
+
+    def encode_source(self, data):
+        """z_src = source_learner.backbone(x, edge_index) (models.py:835 / :1133)."""
+        if self.version != "v2":
+            raise NotImplementedError("v1 SAGEConv encoders are a next-tier row (SURVEY.md 8(f) rank 3): pass z_src=")
+        return self._mlp_encoder(data.x.to(self.device).float(), "source_learner.backbone.")
+
+    def encode_target(self, data):
+        """z_tar, _ = target_learner.encode(data) (models.py:1092-1096)."""
+        if self.version != "v2":
+            raise NotImplementedError("v1 SAGEConv encoders are a next-tier row (SURVEY.md 8(f) rank 3): pass z_tar=")
+        sd = self.sd
+        h0 = F.linear(data.x.to(self.device).float(), sd["target_learner.equavilent_trans_layer.0.weight"],
+                      sd["target_learner.equavilent_trans_layer.0.bias"])
+        h0 = torch.tanh(self._pairnorm(h0))
+        return self._mlp_encoder(h0, "target_learner.encoder.")
+
+    def class_probs(self, z):
+        """exp(log_softmax(lin_clf(relu(z)))) -- models.py:136-140, :842 (dropout is identity in eval)."""
+        if not self.use_clf:
+            return None
+        return F.softmax(F.linear(F.relu(z), self.sim["lin_clf.weight"], self.sim["lin_clf.bias"]), dim=-1)
+
+    # ---- per-node halves of the pair scorers ---------------------------------------------------
+    def cosine_q(self, z):
+        """q = u + biasatt(u), u = lin_self(z), eval-mode BN (models.py:93-99, :70-74, :125-127)."""
+        if self.sim_mode == "cosine_notrans":
+            return z.contiguous()
+        s = self.sim
+        a0, c0 = _bn_affine(s, "lin_self.0.")
+        u = F.linear(z * a0 + c0, s["lin_self.1.weight"])
+        a2, c2 = _bn_affine(s, "lin_self.2.")
+        u = F.linear(torch.tanh(u * a2 + c2), s["lin_self.4.weight"])
+        b = F.linear(torch.tanh(F.linear(u, s["biasatt.0.weight"], s["biasatt.0.bias"])),
+                     s["biasatt.2.weight"], s["biasatt.2.bias"])
+        return (u + b).contiguous()
+
+    def mlp_terms(self, z_cand, z_query):
+        """A[cand], B[query], bn2 scale/shift, w2, b2 (models.py:918-925, :949-951); first half of the
+        concatenation is the idx1 ('from'/candidate) side."""
+        s = self.sim
+        h = z_cand.shape[1]
+        a, c = _bn_affine(s, "lin_self.0.")
+        W1, b1 = s["lin_self.1.weight"], s["lin_self.1.bias"]
+        A = F.linear(z_cand * a[:h] + c[:h], W1[:, :h])
+        B = F.linear(z_query * a[h:] + c[h:], W1[:, h:], b1)
+        scale, shift = _bn_affine(s, "lin_self.2.")
+        return (A.contiguous(), B.contiguous(), scale.contiguous(), shift.contiguous(),
+                s["lin_self.4.weight"].reshape(-1).contiguous(), float(s["lin_self.4.bias"].reshape(-1)[0].item()))
+
+    def topk(self, z_cand, z_query, k):
+        """-> (idx [Nq,k] int64, probs [Nq,k] fp32, n_fallback) ; rows sorted by (score desc, idx asc)."""
+        if self.sim_mode == "mlp":
+            A, B, scale, shift, w2, b2 = self.mlp_terms(z_cand, z_query)
+            return ops.mlp_pair_topk(A, B, scale, shift, w2, b2, k, apply_sigmoid=True)
+        qc = ops.l2_normalize_rows(self.cosine_q(z_cand))
+        qq = qc if z_query is z_cand else ops.l2_normalize_rows(self.cosine_q(z_query))
+        return ops.cosine_topk(qq, qc, k, apply_sigmoid=True)
+
+    # ---- reference-shaped entry points (explicit pair lists; small inputs / API parity) ---------
+    def pair_probs(self, z1, z2, idx1, idx2):
+        if self.sim_mode == "mlp":
+            A, B, scale, shift, w2, b2 = self.mlp_terms(z1, z2)
+            t = F.relu((A[idx1] + B[idx2]) * scale + shift)
+            return torch.sigmoid(t @ w2 + b2)
+        q1, q2 = self.cosine_q(z1), self.cosine_q(z2)
+        return torch.sigmoid(F.cosine_similarity(q1[idx1], q2[idx2], dim=1, eps=1e-8))
+
+    def get_probs_cross_domain(self, data_src, data_tar, idx1, idx2, return_representation=False):
+        """models/models.py:834-844 / :1132-1142"""
+        z_src, z_tar = self.encode_source(data_src), self.encode_target(data_tar)
+        probs = self.pair_probs(z_src, z_tar, idx1, idx2).unsqueeze(-1)
+        out = (probs, self.class_probs(z_src), self.class_probs(z_tar))
+        return out + (z_src, z_tar) if return_representation else out
+
+    def get_probs_within_domain(self, data, idx1, idx2, domain="target"):
+        """models/models.py:824-833 / :1122-1131"""
+        z = self.encode_source(data) if domain == "source" else self.encode_target(data)
+        return self.pair_probs(z, z, idx1, idx2).unsqueeze(-1), self.class_probs(z)
+
+
+def _homophily(y_from, y_to, edge_index):
+    lab = (y_from[edge_index[0]] != -1) & (y_to[edge_index[1]] != -1)
+    same = (y_from[edge_index[0]] == y_to[edge_index[1]]) & lab
+    return (same.sum() / lab.sum()).item() if int(lab.sum()) > 0 else float("nan")
+
+
+def add_topk_sim_cross_domain_edges(data_src, data_tar, model, epsilon=0.5, k=3, batch_size=1000,
+                                    z_src=None, z_tar=None, verbose=True):
+    """main_bridged_graph.py:33-75.  Returns (coalesced edge_index [2,E] (row0 = source id, row1 =
+    target id), e_sim_mat [Nt,k] sigmoid probs in top-k order, idx_src_mat [Nt,k] int64,
+    probs_clf_src [Ns,C], probs_clf_tar [Nt,C]); all CUDA tensors."""
+    z_src = model.encode_source(data_src) if z_src is None else z_src.to(model.device).float()
+    z_tar = model.encode_target(data_tar) if z_tar is None else z_tar.to(model.device).float()
+    idx, probs, _ = model.topk(z_src.contiguous(), z_tar.contiguous(), k)
+    edge_index_added = ops.topk_edges(idx)                                     # :61-68
+    if verbose and hasattr(data_src, "y") and hasattr(data_tar, "y"):
+        ys, yt = data_src.y.to(model.device), data_tar.y.to(model.device)
+        print("Current homophily ratio:", _homophily(ys, yt, edge_index_added))  # :71-74
+    return (ops.coalesce(edge_index_added), probs, idx,                        # :75
+            model.class_probs(z_src), model.class_probs(z_tar))
+
+
+def add_topk_sim_within_domain_edges(data_src, model, k=3, batch_size=1000, domain="source", z=None, verbose=True):
+    """main_bridged_graph.py:77-120.  Candidates = all nodes of the domain INCLUDING the query itself
+    (the reference does not remove self matches).  Returns (coalesced
+    edge_index (from = top-k idx, to = query), e_sim_mat [n,k], idx_mat [n,k])."""
+    if z is None:
+        z = model.encode_source(data_src) if domain == "source" else model.encode_target(data_src)
+    z = z.to(model.device).float().contiguous()
+    idx, probs, _ = model.topk(z, z, k)
+    ei = ops.coalesce(ops.topk_edges(idx))                                     # :112-113
+    if verbose and hasattr(data_src, "y"):
+        y = data_src.y.to(model.device)
+        print("Current homophily ratio of Graph:", _homophily(y, y, ei))       # :116-119
+    return ei, probs, idx
+
+
+def merge_graphs(data_src, data_tar, edge_index_cross_added, edge_index_added_src=None, edge_index_added_tar=None):
+    """main_bridged_graph.py:163-193: node order [sources ; targets]; returns the coalesced bridged
+    `Data` (x, edge_index, y, train/val/test/central masks) on the device of the edge tensors.
+    Unlike the reference (:170) the cross-edge argument is NOT modified in place."""
+    dev = edge_index_cross_added.device
+    ns, nt = data_src.x.shape[0], data_tar.x.shape[0]
+    n = ns + nt
+    parts = [data_src.edge_index.to(dev), data_tar.edge_index.to(dev) + ns,
+             torch.stack([edge_index_cross_added[0], edge_index_cross_added[1] + ns])]
+    if edge_index_added_src is not None:
+        parts.append(edge_index_added_src.to(dev))
+    if edge_index_added_tar is not None:
+        parts.append(edge_index_added_tar.to(dev) + ns)
+    edge_index = ops.coalesce(torch.cat(parts, dim=1), n)                      # :193 Data(...).coalesce()
+    central = torch.zeros(n, dtype=torch.bool, device=dev)
+    central[:ns] = True
+    ys, yt = data_src.y.to(dev), data_tar.y.to(dev)
+    train = central.clone()
+    train[:ns] &= ys != -1                                                     # :186-187
+    val = torch.zeros(n, dtype=torch.bool, device=dev)
+    test = torch.zeros(n, dtype=torch.bool, device=dev)
+    if hasattr(data_tar, "train_mask"):
+        train[ns:] = data_tar.train_mask.to(dev)                               # :188
+    if hasattr(data_tar, "val_mask"):
+        val[ns:] = data_tar.val_mask.to(dev)                                   # :189
+    if hasattr(data_tar, "test_mask"):
+        test[ns:] = data_tar.test_mask.to(dev)                                 # :190
+    return Data(x=torch.cat((data_src.x.to(dev), data_tar.x.to(dev)), dim=0), edge_index=edge_index,
+                y=torch.cat((ys, yt), dim=0), train_mask=train, val_mask=val, test_mask=test, central_mask=central)

@@ -1,0 +1,217 @@
+// Fused AdaptedConv attention + aggregation for gfx950 (wave64).
+//
+// Replaces (reference, Bridged-GNN/models/KTGNN.py): the per-edge GATv2 pre-activation gathers
+// :292-293, the attention GEMVs :294-295, torch_geometric.utils.softmax :298-299 (scatter-max,
+// exp, scatter-add, divide) and the two MessagePassing.propagate scatter-adds :303-305 / message
+// :317-319 -- about eight passes over [E',D] temporaries -- by ONE pass over a by-destination CSR
+// with an online softmax.  HBM-bound: algorithmic bytes = E'(4D+4) + N(8D+4).
+//
+// Mapping: a "group" of GL = LF*EP consecutive lanes owns one destination row.  LF lanes span the
+// feature dimension (float4 per lane, LF*4 >= D); EP sub-groups walk different in-edges of the
+// row (edge-parallel, for narrow rows); each sub-group keeps U neighbour rows in flight.
+//   D=128: LF=32, EP=1 -> 2 rows per wave, 8 x 512 B gathers in flight per wave.
+//   D=4  : LF=1,  EP=8 -> 8 rows per wave, each lane owns whole (16-B) neighbour rows.
+// Blocks are persistent over an XCD-contiguous range of row tiles so neighbouring destination
+// rows (which share in-neighbours in a bridged / kNN graph) hit the same XCD's L2.
+#include "bgnn_common.h"
+
+namespace {
+
+struct AggParams {
+  const float* h_t2s;
+  const float* h_s2t;
+  int64_t ldh;
+  const float* a_t2s;
+  const float* a_s2t;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const uint8_t* mask;
+  int64_t n_dst;
+  int32_t D;
+  float slope;
+  float* out;
+  int64_t ldo;
+  float* alpha;
+  const float* ep_scale;
+  const float* ep_shift;
+  int ep_relu;
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int LF, int EP, int U>
+__global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
+  constexpr int GL = LF * EP;            // lanes per destination row
+  constexpr int GPW = 64 / GL;           // rows per wave
+  constexpr int RPB = 4 * GPW;           // rows per block iteration (4 waves)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / GL;               // group inside the wave
+  const int lg = lane % GL;              // lane inside the group
+  const int sub = lg / LF;               // edge-parallel sub-group
+  const int f0 = (lg % LF) * 4;          // first feature column of this lane
+  const bool fvalid = f0 < p.D;          // pad lanes (LF*4 > ldh) never touch memory
+
+  const int64_t ntiles = (p.n_dst + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+
+  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const int64_t i = tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.n_dst;
+    const int64_t ic = rvalid ? i : 0;
+    const bool dom_s = p.mask[ic] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0;
+    const int32_t end = rvalid ? p.rowptr[ic + 1] : 0;
+
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), hi = a4;
+    if (fvalid) {
+      // attention vector is [D] dense: guard the tail when D % 4 != 0
+      a4.x = av[f0];
+      a4.y = f0 + 1 < p.D ? av[f0 + 1] : 0.f;
+      a4.z = f0 + 2 < p.D ? av[f0 + 2] : 0.f;
+      a4.w = f0 + 3 < p.D ? av[f0 + 3] : 0.f;
+      hi = *reinterpret_cast<const float4*>(H + ic * p.ldh + f0);
+    }
+
+    float m = -INFINITY, s = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t deg = end - beg;
+    const int32_t niter = (deg + EP * U - 1) / (EP * U);   // uniform inside the group
+
+    // software pipeline: neighbour ids for the next chunk are fetched while this chunk's rows fly
+    int32_t nid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int32_t e = beg + sub + u * EP;
+      nid[u] = e < end ? p.col[e] : -1;
+    }
+    for (int32_t it = 0; it < niter; ++it) {
+      const int32_t e0 = beg + it * (EP * U) + sub;
+      int32_t id[U];
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        id[u] = nid[u];
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id[u] >= 0 && fvalid) v[u] = *reinterpret_cast<const float4*>(H + (int64_t)id[u] * p.ldh + f0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int32_t e = e0 + (U + u) * EP;
+        nid[u] = e < end ? p.col[e] : -1;
+      }
+      float lg_[U];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float t = a4.x * leaky(v[u].x + hi.x, p.slope);
+        t = fmaf(a4.y, leaky(v[u].y + hi.y, p.slope), t);
+        t = fmaf(a4.z, leaky(v[u].z + hi.z, p.slope), t);
+        t = fmaf(a4.w, leaky(v[u].w + hi.w, p.slope), t);
+        t = bgnn::group_sum<LF>(t);
+        lg_[u] = id[u] >= 0 ? t : -INFINITY;
+        cm = fmaxf(cm, lg_[u]);
+      }
+      if (p.alpha != nullptr && (lg % LF) == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (id[u] >= 0) p.alpha[e0 + u * EP] = lg_[u];       // raw logit, normalised below
+      }
+      const float mn = fmaxf(m, cm);
+      // m == mn covers the (-inf,-inf) start of an empty sub-group without producing NaN
+      const float sc = (m == mn) ? 1.f : __expf(m - mn);
+      s *= sc;
+      acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float pe = (lg_[u] == -INFINITY) ? 0.f : __expf(lg_[u] - mn);
+        s += pe;
+        acc.x = fmaf(pe, v[u].x, acc.x);
+        acc.y = fmaf(pe, v[u].y, acc.y);
+        acc.z = fmaf(pe, v[u].z, acc.z);
+        acc.w = fmaf(pe, v[u].w, acc.w);
+      }
+      m = mn;
+    }
+
+    // merge the EP partial (m, s, acc) states of the row
+#pragma unroll
+    for (int off = LF; off < GL; off <<= 1) {
+      const float m2 = __shfl_xor(m, off);
+      const float s2 = __shfl_xor(s, off);
+      float4 b;
+      b.x = __shfl_xor(acc.x, off); b.y = __shfl_xor(acc.y, off);
+      b.z = __shfl_xor(acc.z, off); b.w = __shfl_xor(acc.w, off);
+      const float mn = fmaxf(m, m2);
+      const float c1 = (m == mn) ? 1.f : __expf(m - mn);
+      const float c2 = (m2 == mn) ? 1.f : __expf(m2 - mn);
+      s = s * c1 + s2 * c2;
+      acc.x = acc.x * c1 + b.x * c2; acc.y = acc.y * c1 + b.y * c2;
+      acc.z = acc.z * c1 + b.z * c2; acc.w = acc.w * c1 + b.w * c2;
+      m = mn;
+    }
+
+    const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
+    if (p.alpha != nullptr && (lg % LF) == 0) {
+      for (int32_t e = beg + sub; e < end; e += EP) p.alpha[e] = __expf(p.alpha[e] - m) * inv;
+    }
+    if (rvalid && sub == 0 && f0 < p.ldo) {
+      float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      if (p.ep_scale != nullptr) {
+        float sc4[4], sh4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = f0 + c < p.D;
+          sc4[c] = ok ? p.ep_scale[f0 + c] : 0.f;
+          sh4[c] = ok ? p.ep_shift[f0 + c] : 0.f;
+        }
+        o.x = fmaf(o.x, sc4[0], sh4[0]); o.y = fmaf(o.y, sc4[1], sh4[1]);
+        o.z = fmaf(o.z, sc4[2], sh4[2]); o.w = fmaf(o.w, sc4[3], sh4[3]);
+      }
+      if (p.ep_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = o;
+    }
+  }
+}
+
+template <int LF, int EP, int U>
+int launch(const AggParams& p, hipStream_t st) {
+  constexpr int RPB = 4 * (64 / (LF * EP));
+  int64_t ntiles = (p.n_dst + RPB - 1) / RPB;
+  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;   // multiple of 8 (XCD split), <= 8/CU
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_kernel<LF, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                              const float* a_t2s, const float* a_s2t,
+                                              const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                              int64_t N_dst, int32_t D, float negative_slope,
+                                              float* out, int64_t ldo, float* alpha_opt,
+                                              const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                              void* stream) {
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
+  if (N_dst < 0 || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
+  if ((ldh & 3) || (ldo & 3) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out))
+    return BGNN_E_ALIGN;
+  if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
+  if (N_dst == 0) return 0;
+  AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, N_dst, D, negative_slope,
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu};
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (D + 3) / 4;   // float4 slots per row
+  if (nv <= 1) return launch<1, 8, 2>(p, st);
+  if (nv <= 2) return launch<2, 4, 2>(p, st);
+  if (nv <= 4) return launch<4, 4, 2>(p, st);
+  if (nv <= 8) return launch<8, 2, 4>(p, st);
+  if (nv <= 16) return launch<16, 2, 4>(p, st);
+  if (nv <= 32) return launch<32, 1, 4>(p, st);
+  return launch<64, 1, 4>(p, st);
+}

@@ -1,0 +1,66 @@
+// Shared helpers for the gfx950 kernels (wave64, DPP cross-lane, error plumbing).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bgnn.h"
+
+#define BGNN_LAUNCH_CHECK()                         \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+static inline bool bgnn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t bgnn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+namespace bgnn {
+
+// ---- cross-lane moves without LDS traffic (gfx9 DPP controls) ----------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swz_xor16(float x) {  // lane ^ 16 inside each 32-lane half
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+}
+
+// all-reduce (sum) over aligned groups of LF consecutive lanes, LF in {1,2,4,...,64}
+template <int LF>
+__device__ __forceinline__ float group_sum(float x) {
+  if constexpr (LF >= 2) x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]  : lane^1
+  if constexpr (LF >= 4) x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]  : lane^2
+  if constexpr (LF >= 8) x += dpp_mov<0x141>(x);   // row_half_mirror      : other quad of the 8
+  if constexpr (LF >= 16) x += dpp_mov<0x140>(x);  // row_mirror           : other 8 of the 16
+  if constexpr (LF >= 32) x += swz_xor16(x);       // other 16 of the 32
+  if constexpr (LF >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+template <int LF>
+__device__ __forceinline__ float group_max(float x) {
+  if constexpr (LF >= 2) x = fmaxf(x, dpp_mov<0xB1>(x));
+  if constexpr (LF >= 4) x = fmaxf(x, dpp_mov<0x4E>(x));
+  if constexpr (LF >= 8) x = fmaxf(x, dpp_mov<0x141>(x));
+  if constexpr (LF >= 16) x = fmaxf(x, dpp_mov<0x140>(x));
+  if constexpr (LF >= 32) x = fmaxf(x, swz_xor16(x));
+  if constexpr (LF >= 64) x = fmaxf(x, __shfl_xor(x, 32));
+  return x;
+}
+
+// XCD-aware work split: block b runs on XCD (b % 8) (round-robin dispatch, speed only); give each
+// XCD one contiguous eighth of the tile range so neighbouring tiles share that XCD's L2.
+struct XcdRange {
+  int64_t begin, end, step;
+};
+__device__ __forceinline__ XcdRange xcd_tile_range(int64_t ntiles) {
+  const int nx = 8;
+  int64_t per = (ntiles + nx - 1) / nx;
+  int x = blockIdx.x % nx;
+  int64_t slot = blockIdx.x / nx, nslots = (gridDim.x + nx - 1 - x) / nx;  // blocks landing on this XCD
+  XcdRange r;
+  r.begin = x * per + slot;
+  r.end = min((int64_t)(x + 1) * per, ntiles);
+  r.step = nslots;
+  return r;
+}
+
+}  // namespace bgnn

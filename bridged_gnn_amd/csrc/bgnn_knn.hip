@@ -1,0 +1,660 @@
+// kNN bridge construction on gfx950: pair scoring + per-query top-k, never materialising the
+// pair list (reference: Bridged-GNN/main_bridged_graph.py:45-67 / :90-111 batched loops,
+// pair_enumeration models/models.py:265-282, scorers :124-130 (cosine) and :944-954 (mlp),
+// Tensor.topk call sites main_bridged_graph.py:60,:104).
+//
+// Three passes (see include/bgnn.h for the contract):
+//   1. stream every candidate against a block of queries, fp32 scores (cosine: v_mfma_f32_32x32x2_f32
+//      tiles, candidates = A operand so that one lane holds 16 scores of ONE query -> a single
+//      threshold register per lane; mlp: VALU), keep a KP-entry shortlist per query in LDS
+//      (threshold filter + rare wave-wide bitonic compaction);
+//   2. re-score the shortlist in CANONICAL arithmetic (fp64, feature-index order), rank by
+//      (score desc, index asc), and prove by an error-bound margin that the exact top-k lies inside
+//      the shortlist; unproven rows are queued;
+//   3. queued rows are re-done exhaustively in canonical arithmetic.
+// Index results are therefore bit-identical to oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk.
+#include "bgnn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
+constexpr int WAVES = 4;
+constexpr int QPB = QPW * WAVES;   // queries per block
+constexpr int CT = 32;             // candidates per MFMA tile
+
+// ---- sortable keys: larger key = better (higher score, then LOWER candidate index) --------------
+__device__ __forceinline__ uint32_t ord_f32(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ u64 make_key(float s, int32_t idx) {
+  return ((u64)ord_f32(s) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)idx);
+}
+__device__ __forceinline__ int32_t key_idx(u64 k) { return (int32_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu)); }
+__device__ __forceinline__ float key_score(u64 k) { return unord_f32((uint32_t)(k >> 32)); }
+constexpr u64 KEY_EMPTY = 0ull;    // below every real key (ord(-inf) = 0x007FFFFF > 0)
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return ((u64)hi << 32) | lo;
+}
+
+// wave-wide bitonic sort, DESCENDING, of 64*EPL keys (element e of lane l has global index l + 64*e)
+template <int EPL>
+__device__ __forceinline__ void wave_sort_desc(u64 (&v)[EPL], int lane) {
+  constexpr int NTOT = 64 * EPL;
+#pragma unroll
+  for (int k = 2; k <= NTOT; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {   // partner lives in the same lane (only EPL == 2, j == 64)
+        const int i0 = lane, i1 = lane + 64;
+        const bool desc = ((i0 & k) == 0);   // k == 128 here -> always true
+        u64 a = v[0], b = v[EPL - 1];
+        const bool sw = desc ? (a < b) : (a > b);
+        if (sw) { v[0] = b; v[EPL - 1] = a; }
+        (void)i1;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int i = lane + 64 * e;
+          const u64 o = shfl_xor_u64(v[e], j);
+          const bool desc = ((i & k) == 0);
+          const bool lower = ((i & j) == 0);          // I am the lower index of the pair
+          // descending block: lower index keeps the max
+          const bool keep_max = (desc == lower);
+          v[e] = keep_max ? (v[e] > o ? v[e] : o) : (v[e] < o ? v[e] : o);
+        }
+      }
+    }
+  }
+}
+
+// ---- per-wave shortlist state in LDS -----------------------------------------------------------
+template <int EPL>
+struct WaveTopK {
+  static constexpr int CAP = 64 * EPL;   // buffer entries per query
+  static constexpr int KP = CAP / 2;     // live shortlist size
+  u64* keys;                             // [QPW][CAP]
+  int* cnt;                              // [QPW]
+  float* tau;                            // [QPW]  current admission threshold (score of the KP-th best)
+
+  __device__ __forceinline__ void init(int lane) {
+    for (int t = lane; t < QPW * CAP; t += 64) keys[t] = KEY_EMPTY;
+    if (lane < QPW) { cnt[lane] = 0; tau[lane] = -INFINITY; }
+  }
+  // sort query q's buffer, keep the best KP, refresh tau.  Called by the whole wave (uniform q).
+  __device__ __forceinline__ void compact(int q, int lane) {
+    u64 v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = keys[q * CAP + lane + 64 * e];
+    const int n = min(cnt[q], CAP);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) if (lane + 64 * e >= n) v[e] = KEY_EMPTY;
+    wave_sort_desc<EPL>(v, lane);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) keys[q * CAP + lane + 64 * e] = v[e];
+    // KP-th best sits at global index KP-1: lane (KP-1)%64, element (KP-1)/64
+    constexpr int TL = (KP - 1) % 64, TE = (KP - 1) / 64;
+    const uint32_t kb = __shfl((uint32_t)(v[TE] >> 32), TL);
+    if (lane == 0) {
+      const int nn = n < KP ? n : KP;
+      cnt[q] = nn;
+      tau[q] = (n >= KP) ? unord_f32(kb) : -INFINITY;
+    }
+  }
+};
+
+// Offer the 16 scores a lane holds (one query q = lane&31, candidates cand(r)) to the shortlist.
+template <int EPL>
+__device__ __forceinline__ void offer_tile(WaveTopK<EPL>& tk, const f32x16& acc, int cbase, int64_t Nc, int lane,
+                                           float& tau) {
+  constexpr int CAP = WaveTopK<EPL>::CAP;
+  const int q = lane & 31, h = lane >> 5;
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) any |= acc[r] > tau;
+  if (!__any(any)) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int cand = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    bool pass = (acc[r] > tau) && (cand < Nc);
+    int guard = 0;
+    while (__any(pass)) {
+      if (pass) {
+        const int slot = atomicAdd(&tk.cnt[q], 1);
+        if (slot < CAP) { tk.keys[q * CAP + slot] = make_key(acc[r], cand); pass = false; }
+      }
+      const unsigned long long over = __ballot(pass);
+      if (over) {
+        // rows that overflowed: compact each (wave-uniform loop over the distinct queries)
+        unsigned int qmask = (unsigned int)(over | (over >> 32));
+        while (qmask) {
+          const int qq = __ffs(qmask) - 1;
+          qmask &= qmask - 1;
+          tk.compact(qq, lane);
+        }
+        tau = tk.tau[q];
+        pass = pass && (acc[r] > tau);
+      }
+      if (++guard > 4) break;   // cannot trigger: after a compaction CAP-KP >= 32 slots are free
+    }
+  }
+}
+
+// final: sort each query's buffer and emit the best KP (score, idx) pairs, descending
+template <int EPL>
+__device__ __forceinline__ void emit_shortlists(WaveTopK<EPL>& tk, int lane, int64_t q0, int64_t Nq,
+                                                float* __restrict__ sl_score, int32_t* __restrict__ sl_idx,
+                                                int split, int nsplit) {
+  constexpr int CAP = WaveTopK<EPL>::CAP, KP = WaveTopK<EPL>::KP;
+  for (int q = 0; q < QPW; ++q) {
+    tk.compact(q, lane);
+    const int64_t gq = q0 + q;
+    if (gq < Nq) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int pos = lane + 64 * e;
+        if (pos < KP) {
+          const u64 k = tk.keys[q * CAP + pos];
+          const int64_t o = (gq * nsplit + split) * KP + pos;
+          sl_score[o] = (k == KEY_EMPTY) ? -INFINITY : key_score(k);
+          sl_idx[o] = (k == KEY_EMPTY) ? -1 : key_idx(k);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1, cosine: scores = Qn_cand_tile (A, 32 x d) . Qn_query_block^T (B, d x 32) on fp32 MFMA.
+// DK = d / 8.  LDS: CHUNK x (d+4) floats staging (register-prefetched) + per-wave shortlists.
+template <int DK, int EPL>
+__global__ __launch_bounds__(256, 1) void cosine_pass1_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
+                                                              int64_t Nq, int64_t Nc, int nsplit,
+                                                              float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  constexpr int D = DK * 8, LD = D + 4;
+  constexpr int CAP = WaveTopK<EPL>::CAP;
+  constexpr int CHUNK = EPL == 1 ? 64 : 32;     // candidates staged per barrier pair
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* stage = reinterpret_cast<float*>(smem);                               // [CHUNK][LD]
+  u64* keys_all = reinterpret_cast<u64*>(smem + sizeof(float) * CHUNK * LD);   // [WAVES][QPW][CAP]
+  int* cnt_all = reinterpret_cast<int*>(keys_all + WAVES * QPW * CAP);
+  float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
+  // candidate range of this split (multiple of 64 so tiles never straddle splits)
+  const int64_t per = ((Nc + nsplit - 1) / nsplit + 63) / 64 * 64;
+  const int64_t c_begin = min((int64_t)split * per, Nc), c_end = min(c_begin + per, Nc);
+
+  WaveTopK<EPL> tk;
+  tk.keys = keys_all + wave * QPW * CAP;
+  tk.cnt = cnt_all + wave * QPW;
+  tk.tau = tau_all + wave * QPW;
+  tk.init(lane);
+
+  // B fragments (this wave's 32 queries), resident for the whole kernel:
+  // lane (j = lane&31, h = lane>>5) holds q[j][8kb + 4h + s], s = 0..3
+  float4 bq[DK];
+  {
+    const int64_t gq = q0 + (lane & 31);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int kb = 0; kb < DK; ++kb)
+      bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // staging: CHUNK x D floats = CHUNK*D/4 float4 over 256 threads
+  constexpr int F4_PER_ROW = D / 4;
+  constexpr int NLD = CHUNK * F4_PER_ROW / 256;
+  static_assert(CHUNK * F4_PER_ROW % 256 == 0 && NLD >= 1, "staging split");
+  float4 pre[NLD];
+  auto gload = [&](int64_t cb) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      const int64_t gc = cb + r;
+      pre[j] = gc < c_end ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) = pre[j];
+    }
+  };
+
+  float tau = -INFINITY;
+  const int fr = lane & 31, fh = lane >> 5;
+  if (c_begin < c_end) gload(c_begin);
+  for (int64_t cb = c_begin; cb < c_end; cb += CHUNK) {
+    sstore();
+    __syncthreads();
+    if (cb + CHUNK < c_end) gload(cb + CHUNK);     // next chunk flies while this one is scored
+#pragma unroll
+    for (int t = 0; t < CHUNK / CT; ++t) {
+      if (cb + t * CT < c_end) {      // block-uniform
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = &stage[(t * CT + fr) * LD + fh * 4];
+#pragma unroll
+        for (int kb = 0; kb < DK; ++kb) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
+        }
+        offer_tile<EPL>(tk, acc, (int)(cb + t * CT), c_end, lane, tau);
+      }
+    }
+    __syncthreads();
+  }
+  emit_shortlists<EPL>(tk, lane, q0, Nq, sl_score, sl_idx, split, nsplit);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1, mlp (Similar_v2 'mlp' in separable eval form, H = 128): fp32 VALU scoring, same shortlist.
+constexpr int MLP_H = 128;
+template <int EPL>
+__global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ w2, float b2, int64_t Nq, int64_t Nc,
+                                                           float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  constexpr int H = MLP_H, LD = H + 4;
+  constexpr int CAP = WaveTopK<EPL>::CAP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* stage = reinterpret_cast<float*>(smem);                                    // [CT][LD]
+  float* coefs = stage + CT * LD;                                                   // scale|shift|w2 [3][H]
+  u64* keys_all = reinterpret_cast<u64*>(coefs + 3 * H);
+  int* cnt_all = reinterpret_cast<int*>(keys_all + WAVES * QPW * CAP);
+  float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
+  WaveTopK<EPL> tk;
+  tk.keys = keys_all + wave * QPW * CAP;
+  tk.cnt = cnt_all + wave * QPW;
+  tk.tau = tau_all + wave * QPW;
+  tk.init(lane);
+  for (int t = tid; t < H; t += 256) { coefs[t] = scale[t]; coefs[H + t] = shift[t]; coefs[2 * H + t] = w2[t]; }
+  float4 bqv[H / 4];                 // this lane's query row B[q][:], statically indexed (registers)
+  {
+    const int64_t gq = q0 + (lane & 31);
+#pragma unroll
+    for (int h4 = 0; h4 < H / 4; ++h4)
+      bqv[h4] = gq < Nq ? *reinterpret_cast<const float4*>(B + gq * H + h4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float tau = -INFINITY;
+  const int fh = lane >> 5;
+  const float4* sc4 = reinterpret_cast<const float4*>(coefs);
+  const float4* sh4 = reinterpret_cast<const float4*>(coefs + H);
+  const float4* w4 = reinterpret_cast<const float4*>(coefs + 2 * H);
+  for (int64_t cb = 0; cb < Nc; cb += CT) {
+    __syncthreads();
+    for (int f = tid; f < CT * (H / 4); f += 256) {
+      const int r = f / (H / 4), c4 = f % (H / 4);
+      const int64_t gc = cb + r;
+      *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) =
+          gc < Nc ? *reinterpret_cast<const float4*>(A + gc * H + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b2;
+#pragma unroll
+    for (int h4 = 0; h4 < H / 4; ++h4) {
+      const float4 sc = sc4[h4], sh = sh4[h4], w = w4[h4], bb = bqv[h4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const float4 a = *reinterpret_cast<const float4*>(&stage[cr * LD + h4 * 4]);
+        acc[r] = fmaf(w.x, fmaxf(fmaf(sc.x, a.x + bb.x, sh.x), 0.f), acc[r]);
+        acc[r] = fmaf(w.y, fmaxf(fmaf(sc.y, a.y + bb.y, sh.y), 0.f), acc[r]);
+        acc[r] = fmaf(w.z, fmaxf(fmaf(sc.z, a.z + bb.z, sh.z), 0.f), acc[r]);
+        acc[r] = fmaf(w.w, fmaxf(fmaf(sc.w, a.w + bb.w, sh.w), 0.f), acc[r]);
+      }
+    }
+    offer_tile<EPL>(tk, acc, (int)cb, Nc, lane, tau);
+  }
+  emit_shortlists<EPL>(tk, lane, q0, Nq, sl_score, sl_idx, 0, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// canonical scores (identical arithmetic to oracle/oracle_c.c)
+struct CosineCanon {
+  const float* qq; const float* qc; int d;
+  __device__ __forceinline__ double operator()(int64_t q, int64_t c) const {
+    const float* a = qq + q * d;
+    const float* b = qc + c * d;
+    double s = 0.0;
+    for (int t = 0; t < d; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(a + t);
+      const float4 y = *reinterpret_cast<const float4*>(b + t);
+      s = s + (double)x.x * (double)y.x;     // products of fp32 are exact in fp64: fma == mul+add
+      s = s + (double)x.y * (double)y.y;
+      s = s + (double)x.z * (double)y.z;
+      s = s + (double)x.w * (double)y.w;
+    }
+    return s;
+  }
+};
+struct MlpCanon {
+  const float* A; const float* B; const float* scale; const float* shift; const float* w2; float b2; int H;
+  __device__ __forceinline__ double operator()(int64_t q, int64_t c) const {
+    const float* a = A + c * H;
+    const float* b = B + q * H;
+    double s = 0.0;
+    for (int h = 0; h < H; ++h) {
+      // fp64 mul/add kept un-fused (non-exact products): matches gcc -ffp-contract=off
+      double u = __dadd_rn((double)b[h], (double)a[h]);
+      double t = __dadd_rn(__dmul_rn((double)scale[h], u), (double)shift[h]);
+      if (t < 0.0) t = 0.0;
+      s = __dadd_rn(s, __dmul_rn((double)w2[h], t));
+    }
+    return __dadd_rn(s, (double)b2);
+  }
+};
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf(-x)); }
+
+// pass 2: one wave per query.  L = nsplit*KP shortlist entries.
+template <class Canon>
+__global__ __launch_bounds__(256) void refine_kernel(Canon canon, int64_t Nq, int k, int L, int KP, int nsplit,
+                                                     const float* __restrict__ sl_score, const int32_t* __restrict__ sl_idx,
+                                                     double err_abs, double err_rel, int apply_sigmoid,
+                                                     int64_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                     int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* es = reinterpret_cast<double*>(smem) + (size_t)wave * L;                        // exact scores
+  int32_t* ei = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(smem) + (size_t)4 * L) + (size_t)wave * L;
+  for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < Nq; q += (int64_t)gridDim.x * 4) {
+    float alast = -INFINITY;   // best approximate score any excluded candidate can have
+    for (int e = lane; e < L; e += 64) {
+      const int32_t c = sl_idx[q * L + e];
+      ei[e] = c;
+      es[e] = c >= 0 ? canon(q, c) : -INFINITY;
+      if ((e % KP) == KP - 1 && c >= 0) alast = fmaxf(alast, sl_score[q * L + e]);   // full split
+    }
+    alast = bgnn::group_max<64>(alast);
+    __builtin_amdgcn_s_waitcnt(0);   // LDS writes above complete before the cross-lane reads below
+    __builtin_amdgcn_wave_barrier();
+    double kth = -INFINITY;
+    for (int e = lane; e < L; e += 64) {
+      const double s = es[e];
+      const int32_t c = ei[e];
+      int rank = 0;
+      if (c >= 0) {
+        for (int j = 0; j < L; ++j) {
+          const double sj = es[j];
+          const int32_t cj = ei[j];
+          rank += (cj >= 0) && (sj > s || (sj == s && cj < c));
+        }
+        if (rank < k) {
+          idx_out[q * k + rank] = c;
+          val_out[q * k + rank] = apply_sigmoid ? sigmoid_f32((float)s) : (float)s;
+        }
+        if (rank == k - 1) kth = s;
+      }
+    }
+    // broadcast kth (exactly one lane holds it when >= k valid entries exist)
+    double kmax = kth;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double other = __shfl_xor(kmax, o);
+      kmax = other > kmax ? other : kmax;
+    }
+    const bool have = kmax > -INFINITY;
+    // proof: every excluded candidate has exact score <= alast + bound < kth
+    const double bound = err_abs + err_rel * fabs((double)alast);
+    const bool proven = (alast == -INFINITY) || (have && kmax > (double)alast + bound);
+    if (!proven && lane == 0) {
+      const int slot = atomicAdd(fb_count, 1);
+      fb_list[slot] = (int32_t)q;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// pass 3: exhaustive canonical re-do of queued rows.  One block per queued row (grid-strided).
+template <class Canon>
+__global__ __launch_bounds__(256) void fallback_kernel(Canon canon, int64_t Nc, int k, int apply_sigmoid,
+                                                       const int32_t* __restrict__ fb_list, const int32_t* __restrict__ fb_count,
+                                                       double* __restrict__ scratch /*[gridDim.x][Nc]*/,
+                                                       int64_t* __restrict__ idx_out, float* __restrict__ val_out) {
+  __shared__ double red_s[256];
+  __shared__ int32_t red_i[256];
+  __shared__ double prev_s;
+  __shared__ int32_t prev_i;
+  const int n = *fb_count;
+  double* sc = scratch + (size_t)blockIdx.x * Nc;
+  for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    const int64_t q = fb_list[it];
+    for (int64_t c = threadIdx.x; c < Nc; c += 256) sc[c] = canon(q, c);
+    if (threadIdx.x == 0) { prev_s = INFINITY; prev_i = -1; }
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+      const double ps = prev_s;
+      const int32_t pi = prev_i;
+      double bs = -INFINITY;
+      int32_t bi = 0x7FFFFFFF;
+      for (int64_t c = threadIdx.x; c < Nc; c += 256) {
+        const double s = sc[c];
+        // strictly after (ps, pi) in (score desc, index asc) order
+        const bool after = (s < ps) || (s == ps && (int32_t)c > pi);
+        if (after && (s > bs || (s == bs && (int32_t)c < bi))) { bs = s; bi = (int32_t)c; }
+      }
+      red_s[threadIdx.x] = bs;
+      red_i[threadIdx.x] = bi;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+          const double s2 = red_s[threadIdx.x + o];
+          const int32_t i2 = red_i[threadIdx.x + o];
+          if (s2 > red_s[threadIdx.x] || (s2 == red_s[threadIdx.x] && i2 < red_i[threadIdx.x])) {
+            red_s[threadIdx.x] = s2;
+            red_i[threadIdx.x] = i2;
+          }
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        const bool ok = red_i[0] != 0x7FFFFFFF;
+        idx_out[q * k + r] = ok ? red_i[0] : -1;
+        const float v = (float)red_s[0];
+        val_out[q * k + r] = ok ? (apply_sigmoid ? sigmoid_f32(v) : v) : -INFINITY;
+        prev_s = red_s[0];
+        prev_i = ok ? red_i[0] : 0x7FFFFFFF;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void normalize_rows_kernel(const float* __restrict__ q, int64_t n, int d, float eps, float* __restrict__ out) {
+  // canonical: fp64 sum of squares in index order, fp64 sqrt, round to fp32, clamp, IEEE fp32 divide
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = q + i * d;
+  double s = 0.0;
+  for (int c = 0; c < d; ++c) { const double v = (double)r[c]; s = s + v * v; }
+  float nr = (float)sqrt(s);
+  if (!(nr > eps)) nr = eps;
+  for (int c = 0; c < d; ++c) out[i * d + c] = __fdiv_rn(r[c], nr);
+}
+
+__global__ void copy_count_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { *dst = *src; }
+
+struct TopkWs {
+  float* sl_score; int32_t* sl_idx; int32_t* fb_list; int32_t* fb_count; double* scratch;
+  int fb_blocks;
+};
+constexpr int FB_BLOCKS = 64;
+constexpr int MAX_SPLIT = 8;
+
+static int pick_nsplit(int64_t Nq, int64_t Nc) {
+  // candidate splits: fill the 256 CUs when there are few query blocks
+  const int64_t qblocks = (Nq + QPB - 1) / QPB;
+  int nsplit = 1;
+  while (nsplit < MAX_SPLIT && qblocks * nsplit < 512 && Nc / (nsplit * 2) >= 4096) nsplit *= 2;
+  return nsplit;
+}
+static int pick_kp(int k) { return k <= 24 ? 32 : 64; }
+
+static size_t topk_ws_bytes(int64_t Nq, int64_t Nc, int k) {
+  const size_t L = (size_t)pick_nsplit(Nq, Nc) * pick_kp(k);
+  size_t b = 0;
+  b += bgnn_align_up(sizeof(float) * Nq * L, 256);
+  b += bgnn_align_up(sizeof(int32_t) * Nq * L, 256);
+  b += bgnn_align_up(sizeof(int32_t) * (Nq + 1), 256);
+  b += 256;
+  b += bgnn_align_up(sizeof(double) * FB_BLOCKS * Nc, 256);
+  return b + 256;
+}
+static TopkWs topk_carve(void* ws, int64_t Nq, int64_t Nc, int k) {
+  const size_t L = (size_t)pick_nsplit(Nq, Nc) * pick_kp(k);
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { char* q = p; p += bgnn_align_up(bytes, 256); return q; };
+  TopkWs w;
+  w.sl_score = (float*)take(sizeof(float) * Nq * L);
+  w.sl_idx = (int32_t*)take(sizeof(int32_t) * Nq * L);
+  w.fb_list = (int32_t*)take(sizeof(int32_t) * (Nq + 1));
+  w.fb_count = (int32_t*)take(256);
+  w.scratch = (double*)take(sizeof(double) * FB_BLOCKS * Nc);
+  w.fb_blocks = FB_BLOCKS;
+  return w;
+}
+
+template <class Canon>
+static int run_refine(const Canon& canon, int64_t Nq, int64_t Nc, int k, int KP, int nsplit, const TopkWs& w,
+                      double err_abs, double err_rel, int apply_sigmoid, int64_t* idx_out, float* val_out,
+                      int32_t* n_fallback_opt, hipStream_t st) {
+  hipError_t e;
+  if ((e = hipMemsetAsync(w.fb_count, 0, sizeof(int32_t), st)) != hipSuccess) return (int)e;
+  const int L = KP * nsplit;
+  int64_t grid = (Nq + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  const size_t sh = (size_t)4 * L * (sizeof(double) + sizeof(int32_t));
+  hipLaunchKernelGGL((refine_kernel<Canon>), dim3((unsigned)grid), dim3(256), sh, st, canon, Nq, k, L, KP, nsplit,
+                     w.sl_score, w.sl_idx, err_abs, err_rel, apply_sigmoid, idx_out, val_out, w.fb_list, w.fb_count);
+  BGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL((fallback_kernel<Canon>), dim3(w.fb_blocks), dim3(256), 0, st, canon, Nc, k, apply_sigmoid,
+                     w.fb_list, w.fb_count, w.scratch, idx_out, val_out);
+  BGNN_LAUNCH_CHECK();
+  if (n_fallback_opt) {
+    hipLaunchKernelGGL(copy_count_kernel, dim3(1), dim3(1), 0, st, w.fb_count, n_fallback_opt);
+    BGNN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <int DK, int EPL>
+static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, int nsplit, const TopkWs& w,
+                               hipStream_t st) {
+  constexpr int D = DK * 8, LD = D + 4, CAP = 64 * EPL, CHUNK = EPL == 1 ? 64 : 32;
+  const size_t sh = sizeof(float) * CHUNK * LD + sizeof(u64) * WAVES * QPW * CAP + sizeof(int) * WAVES * QPW +
+                    sizeof(float) * WAVES * QPW;
+  auto kern = cosine_pass1_kernel<DK, EPL>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((Nq + QPB - 1) / QPB), (unsigned)nsplit), dim3(256), sh, st, qq, qc, Nq, Nc,
+                     nsplit, w.sl_score, w.sl_idx);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bgnn_l2_normalize_rows_f32(const float* q, int64_t n, int32_t d, float eps, float* out, void* stream) {
+  if (!q || !out) return BGNN_E_NULL;
+  if (n < 0 || d <= 0) return BGNN_E_SHAPE;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, n, d, eps, out);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t bgnn_topk_workspace_bytes(int64_t Nq, int64_t Nc, int32_t k) {
+  return topk_ws_bytes(Nq < 1 ? 1 : Nq, Nc < 1 ? 1 : Nc, k);
+}
+
+extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand, int64_t Nq, int64_t Nc,
+                                    int32_t d, int32_t k, int apply_sigmoid, int64_t* idx_out, float* val_out,
+                                    int32_t* n_fallback_opt, void* ws, size_t ws_bytes, void* stream) {
+  if (!qn_query || !qn_cand || !idx_out || !val_out || !ws) return BGNN_E_NULL;
+  if (Nq < 0 || Nc <= 0 || Nc >= (int64_t)1 << 31 || d <= 0) return BGNN_E_SHAPE;
+  if (d != 32 && d != 64 && d != 128 && d != 256) return BGNN_E_SHAPE;   // callers zero-pad d
+  if (k <= 0 || k > 56 || k > Nc) return BGNN_E_RANGE;
+  if (d == 256 && k > 24) return BGNN_E_SHAPE;   // LDS budget (shortlists 128 KB + staging)
+  if (!bgnn_aligned16(qn_query) || !bgnn_aligned16(qn_cand)) return BGNN_E_ALIGN;
+  if (ws_bytes < topk_ws_bytes(Nq, Nc, k)) return BGNN_E_WORKSPACE;
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  TopkWs w = topk_carve(ws, Nq, Nc, k);
+  const int epl = k <= 24 ? 1 : 2;
+  const int KP = 32 * epl;
+  const int nsplit = pick_nsplit(Nq, Nc);
+  int rc;
+#define COS(DKV)                                                                                        \
+  rc = epl == 1 ? launch_cosine_pass1<DKV, 1>(qn_query, qn_cand, Nq, Nc, nsplit, w, st)                 \
+                : launch_cosine_pass1<DKV, 2>(qn_query, qn_cand, Nq, Nc, nsplit, w, st)
+  if (d == 32) { COS(4); } else if (d == 64) { COS(8); } else if (d == 128) { COS(16); } else { COS(32); }
+#undef COS
+  if (rc) return rc;
+  // |fp32 MFMA dot - exact| <= d * 2^-24 * sum|a_c b_c| <= d * 2^-24 for unit vectors (Cauchy-Schwarz);
+  // x2 safety + the fp32 rounding of the stored shortlist score
+  const double err_abs = 2.0 * (double)(d + 2) * 5.9604644775390625e-08;
+  CosineCanon canon{qn_query, qn_cand, d};
+  return run_refine(canon, Nq, Nc, k, KP, nsplit, w, err_abs, 0.0, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
+}
+
+extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query, const float* bn_scale,
+                                      const float* bn_shift, const float* w2, float b2, int64_t Nq, int64_t Nc,
+                                      int32_t H, int32_t k, int apply_sigmoid, int64_t* idx_out, float* val_out,
+                                      int32_t* n_fallback_opt, void* ws, size_t ws_bytes, void* stream) {
+  if (!A_cand || !B_query || !bn_scale || !bn_shift || !w2 || !idx_out || !val_out || !ws) return BGNN_E_NULL;
+  if (Nq < 0 || Nc <= 0 || Nc >= (int64_t)1 << 31) return BGNN_E_SHAPE;
+  if (H != MLP_H) return BGNN_E_SHAPE;   // Similar_v2 'mlp' hidden width is fixed at 128 (models.py:921)
+  if (k <= 0 || k > 56 || k > Nc) return BGNN_E_RANGE;
+  if (!bgnn_aligned16(A_cand) || !bgnn_aligned16(B_query)) return BGNN_E_ALIGN;
+  if (ws_bytes < topk_ws_bytes(Nq, Nc, k)) return BGNN_E_WORKSPACE;
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  TopkWs w = topk_carve(ws, Nq, Nc, k);
+  const int epl = k <= 24 ? 1 : 2;
+  const int KP = 32 * epl;
+  {
+    const int CAP = 64 * epl;
+    const size_t sh = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H) + sizeof(u64) * WAVES * QPW * CAP +
+                      sizeof(int) * WAVES * QPW + sizeof(float) * WAVES * QPW;
+    const unsigned grid = (unsigned)((Nq + QPB - 1) / QPB);
+    hipError_t e;
+    if (epl == 1) {
+      auto kern = mlp_pass1_kernel<1>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, w.sl_score, w.sl_idx);
+    } else {
+      auto kern = mlp_pass1_kernel<2>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, w.sl_score, w.sl_idx);
+    }
+    BGNN_LAUNCH_CHECK();
+  }
+  // fp32 evaluation of a 128-term sum of O(1) terms: relative bound on the logit magnitude plus an
+  // absolute floor; generous (a loose bound only costs a few more exhaustive rows)
+  MlpCanon canon{A_cand, B_query, bn_scale, bn_shift, w2, b2, H};
+  return run_refine(canon, Nq, Nc, k, KP, 1, w, 1e-4, 1e-4, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
+}

@@ -1,0 +1,278 @@
+"""KT-GNN on MI355X: `AdaptedConv` and `KTGNN_no_complement` with the reference's constructor
+arguments, forward signatures and state_dict keys (reference Bridged-GNN/models/KTGNN.py:218-328
+and :330-465), computing through the HIP library (ops.py -> include/bgnn.h).
+
+What is different by design (MI355X-first, results identical within 1e-5 relative):
+  * the cached `(edge_index1, edge_index2)` pair becomes ONE by-destination CSR + the per-row
+    domain flag `central_mask[row]` (KTGNN.py:385-398, :409-412);
+  * gathers / attention GEMVs / PyG softmax / two propagate scatter-adds (:292-305) are one fused
+    kernel; the shifted copies x_s2t / x_t2s (:279-280) are never materialised;
+  * eval-mode BatchNorm1d + ReLU after a hidden conv (:425-430) ride in that kernel's epilogue.
+Backward is not implemented yet: forward under autograd raises.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+__all__ = ["Linear", "AdaptedConv", "KTGNN_no_complement"]
+
+
+class Linear(nn.Module):
+    """Stand-in for `torch_geometric.nn.dense.linear.Linear` (used at KTGNN.py:240-246, :364-367):
+    y = x W^T (+ b), weight [out, in]; kaiming-uniform(a=sqrt(5)) / 'glorot' initialisers."""
+
+    def __init__(self, in_channels, out_channels, bias=True, weight_initializer=None, bias_initializer=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer, self.bias_initializer = weight_initializer, bias_initializer
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight_initializer == "glorot":
+            a = math.sqrt(6.0 / (self.weight.size(-2) + self.weight.size(-1)))
+            nn.init.uniform_(self.weight, -a, a)
+        else:
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            if self.bias_initializer == "zeros":
+                nn.init.zeros_(self.bias)
+            else:
+                bound = 1.0 / math.sqrt(self.in_channels) if self.in_channels > 0 else 0.0
+                nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+def _as_u8(mask):
+    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+
+
+def _pad_cols4(t):
+    """zero-pad the last dim to a multiple of 4 (float4 loads in the kernels)."""
+    pad = (-t.shape[-1]) % 4
+    return t.contiguous() if pad == 0 else F.pad(t, (0, pad)).contiguous()
+
+
+class AdaptedConv(nn.Module):
+    """Reference `AdaptedConv(MessagePassing)` -- models/KTGNN.py:218-328.
+
+    forward(x, edge_index, edge_index1, edge_index2, central_mask, size=None) -> [N, out_channels]
+    `edge_index` is the already-rewritten cat(edge_index1, edge_index2) (what graph_partition
+    returns); the split itself is implied by `central_mask[destination]`.
+    """
+
+    def __init__(self, in_channels, out_channels, normalize=False, root_weight=True, activation_g=None,
+                 negative_slope=0.1, bias=True, **kwargs):
+        super().__init__()
+        kwargs.setdefault("aggr", "add")
+        if kwargs["aggr"] != "add":
+            raise NotImplementedError("AdaptedConv is defined with aggr='add' (KTGNN.py:223)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.normalize, self.root_weight = normalize, root_weight
+        self.activation_g, self.negative_slope = activation_g, negative_slope
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        if self.root_weight:
+            self.lin_r = Linear(in_channels[1], out_channels, bias=False)
+        self.lin_s = Linear(in_channels[0], out_channels, bias=bias)
+        self.lin_t = Linear(in_channels[0], out_channels, bias=bias)
+        self.a_g_s2t = Linear(in_channels[0] * 2, 1, bias=False)
+        self.a_g_t2s = Linear(in_channels[0] * 2, 1, bias=False)
+        self.a_f_s2t = Linear(out_channels, 1, bias=False)
+        self.a_f_t2s = Linear(out_channels, 1, bias=False)
+        self._csr_cache = {}
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.lin_s, self.lin_t, self.a_g_s2t, self.a_g_t2s, self.a_f_s2t, self.a_f_t2s):
+            m.reset_parameters()
+        if self.root_weight:
+            self.lin_r.reset_parameters()
+
+    # -- pieces (also used by the multi-GPU driver in dist.py) ---------------------------------
+    def gate_vectors(self, din_pad):
+        """[x || delta] gate weights split and padded: g[:Din_pad] multiplies x, g[Din_pad:] delta."""
+        din = self.lin_s.weight.shape[1]
+
+        def split(w):
+            w = w.detach().reshape(-1)
+            g = torch.zeros(2 * din_pad, dtype=torch.float32, device=w.device)
+            g[:din] = w[:din]
+            g[din_pad:din_pad + din] = w[din:]
+            return g
+        return split(self.a_g_s2t.weight), split(self.a_g_t2s.weight)
+
+    def transform(self, x, mask_u8, delta=None, sums=None):
+        """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]."""
+        xp = _pad_cols4(x)
+        din_pad = xp.shape[1]
+        if delta is None:
+            if sums is None:
+                sums = ops.domain_sums(xp, mask_u8)
+            delta = ops.domain_delta(sums, din_pad)
+        g_s2t, g_t2s = self.gate_vectors(din_pad)
+        W_s, W_t = _pad_cols4(self.lin_s.weight.detach()), _pad_cols4(self.lin_t.weight.detach())
+        b_s = self.lin_s.bias.detach() if self.lin_s.bias is not None else None
+        b_t = self.lin_t.bias.detach() if self.lin_t.bias is not None else None
+        return ops.adaptedconv_transform(xp, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s)
+
+    def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None):
+        """KTGNN.py:292-305 (+ optional fused BN-eval/ReLU epilogue)."""
+        a_t2s = self.a_f_t2s.weight.detach().reshape(-1).contiguous()
+        a_s2t = self.a_f_s2t.weight.detach().reshape(-1).contiguous()
+        sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
+        return ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, self.out_channels,
+                                         self.negative_slope, n_dst=n_dst, want_alpha=want_alpha,
+                                         ep_scale=sc, ep_shift=sh, ep_relu=relu)
+
+    def _csr_for(self, edge_index, num_nodes):
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index.device.index, num_nodes)
+        csr = self._csr_cache.get(key)
+        if csr is None:
+            # edge_index is ALREADY rewritten by graph_partition -> no self-loop rewrite here
+            csr = ops.build_dst_csr(edge_index, num_nodes, rewrite_self_loops=False)
+            self._csr_cache = {key: csr}
+        return csr
+
+    def forward(self, x, edge_index, edge_index1=None, edge_index2=None, central_mask=None, size=None,
+                csr=None, delta=None, epilogue=None, return_alpha=False):
+        if isinstance(x, (tuple, list)):
+            x_src, x_r = x
+        else:
+            x_src = x_r = x
+        if not x_src.is_cuda:
+            raise RuntimeError("AdaptedConv runs on MI355X only (CUDA/HIP tensors); there is no CPU path")
+        if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "AdaptedConv backward is not implemented yet (SURVEY.md 8(f) rank 1); call under torch.no_grad()")
+        if central_mask is None:
+            raise ValueError("central_mask is required")
+        x_src = x_src.float()
+        N = x_src.shape[0]
+        mask_u8 = _as_u8(central_mask).contiguous()
+        if csr is None:
+            csr = self._csr_for(edge_index, N)
+        h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta)
+        fuse = epilogue if not (self.root_weight or self.normalize) else None
+        res = self.aggregate(h_t2s, h_s2t, csr, mask_u8, want_alpha=return_alpha, epilogue=fuse)
+        out, alpha = res if return_alpha else (res, None)
+        out = out[:, : self.out_channels]
+        if self.root_weight and x_r is not None:
+            out = out + self.lin_r(x_r.float())                      # KTGNN.py:309-310
+        if self.normalize:
+            out = F.normalize(out, p=2.0, dim=-1)                    # :312-313
+        if epilogue is not None and fuse is None:
+            sc, sh, relu = epilogue
+            out = out * sc + sh
+            out = F.relu(out) if relu else out
+        return (out, alpha) if return_alpha else out
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
+
+
+class KTGNN_no_complement(nn.Module):
+    """Reference `KTGNN_no_complement` -- models/KTGNN.py:330-465 (need_complement=False only; every
+    reference call site passes False: main_graph_knowledge_transfer.py:179,:332-333)."""
+
+    def __init__(self, num_features, num_classes=2, layer_num=2, hidden=64, root_weight=False, dim_share=300,
+                 step=1, hidden_o=128, hidden_u=128, use_dist_loss=False, cached_edges=True, dropout=0.5,
+                 use_bn=False, need_complement=False):
+        super().__init__()
+        if need_complement:
+            raise NotImplementedError("Adapted_complementor is out of scope (never enabled by the reference drivers)")
+        self.cached_edges, self.dropout, self.use_bn, self.need_complement = cached_edges, dropout, use_bn, False
+        self.convs = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        dim_in = dim_share
+        if layer_num == 1:
+            self.convs.append(AdaptedConv(dim_in, num_classes, root_weight=root_weight))
+        else:
+            for num in range(layer_num - 1):
+                self.convs.append(AdaptedConv(dim_in if num == 0 else hidden, hidden, root_weight=root_weight))
+                if self.use_bn:
+                    self.bns.append(nn.BatchNorm1d(hidden))
+        self.clf_base = AdaptedConv(hidden, num_classes, root_weight=root_weight)
+        self.clf_target = AdaptedConv(hidden, num_classes, root_weight=root_weight)
+        self.clf_transformer = nn.Sequential(
+            Linear(hidden, hidden, bias=True), nn.BatchNorm1d(hidden), nn.ReLU(), Linear(hidden, hidden, bias=True))
+        self.edge_index1 = self.edge_index2 = self.edge_index = None
+        self._csr = None
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+        self.clf_base.reset_parameters()
+        self.clf_target.reset_parameters()
+        for l in self.clf_transformer:
+            if isinstance(l, (Linear, nn.BatchNorm1d)):
+                l.reset_parameters()
+
+    def graph_partition(self, edge_index, central_mask, add_self_loop=True):
+        """KTGNN.py:385-398: returns (edge_index1, edge_index2, cat) -- kept for API parity; the
+        kernels use the CSR built by `_prepare` instead."""
+        if not edge_index.is_cuda:
+            raise RuntimeError("graph_partition runs on CUDA(HIP) tensors only; there is no CPU path")
+        if add_self_loop:
+            n = central_mask.shape[0]
+            edge_index = edge_index[:, edge_index[0] != edge_index[1]]
+            loop = torch.arange(n, dtype=torch.int64, device=edge_index.device)
+            edge_index = torch.cat([edge_index, torch.stack([loop, loop])], dim=1)
+        m1 = central_mask[edge_index[1]]
+        e1, e2 = edge_index[:, m1], edge_index[:, ~m1]
+        return e1, e2, torch.cat((e1, e2), dim=-1)
+
+    def _prepare(self, data):
+        if self.cached_edges and self._csr is not None:
+            return self._csr
+        csr = ops.build_dst_csr(data.edge_index, data.central_mask.shape[0], rewrite_self_loops=True)
+        if self.cached_edges:
+            self._csr = csr
+        return csr
+
+    def _hidden(self, x, csr, central_mask):
+        for ind, conv in enumerate(self.convs):                                   # :418-430
+            if self.use_bn and not self.training:
+                bn = self.bns[ind]
+                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
+                sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
+                x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True))
+            else:
+                x = conv(x, None, central_mask=central_mask, csr=csr)
+                if self.use_bn:
+                    x = self.bns[ind](x)
+                x = F.relu(x)
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        return x
+
+    def forward(self, data):
+        x, central_mask = data.x, data.central_mask
+        csr = self._prepare(data)
+        x = self._hidden(x, csr, central_mask)
+        x = x.contiguous()
+        # clf_base and clf_target(x) see the same input -> the domain means are shared
+        mask_u8 = _as_u8(central_mask).contiguous()
+        xp = _pad_cols4(x)
+        delta = ops.domain_delta(ops.domain_sums(xp, mask_u8), xp.shape[1])
+        logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr, delta=delta)            # :432
+        xt = self.clf_transformer(x)
+        logits_hat = self.clf_target(xt, None, central_mask=central_mask, csr=csr)                        # :433
+        logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr, delta=delta)         # :434
+        return (F.log_softmax(logits_base, dim=1), F.log_softmax(logits_target, dim=1),
+                F.log_softmax(logits_hat, dim=1), None)                                                  # :435
+
+    def get_emb(self, data):
+        """KTGNN.py:436-465."""
+        return self._hidden(data.x, self._prepare(data), data.central_mask)

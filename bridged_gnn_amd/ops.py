@@ -1,0 +1,181 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/bgnn.h).
+Every function takes/returns CUDA(HIP) tensors on the current device and launches on torch's
+current stream.  No CPU path exists: host tensors raise."""
+import torch
+
+from . import _lib as L
+
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "adaptedconv_transform", "adaptedconv_aggregate",
+           "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "pad4"]
+
+
+def pad4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+class DstCSR:
+    """By-destination CSR of the rewritten edge set: the build's replacement for the cached
+    (edge_index1, edge_index2) pair of `KTGNN_no_complement.graph_partition`
+    (reference models/KTGNN.py:385-398, :409-412).  Domain of a row = central_mask[row]."""
+
+    def __init__(self, rowptr, col, eperm, num_edges, num_nodes):
+        self.rowptr, self.col, self.eperm = rowptr, col, eperm
+        self.num_edges, self.num_nodes = int(num_edges), int(num_nodes)
+
+
+def build_dst_csr(edge_index, num_nodes, rewrite_self_loops=True, want_eperm=False):
+    """edge_index int64 [2,E] (CUDA) -> DstCSR.  One D2H read of E' (the CSR is built once per graph
+    and cached, like the reference caches graph_partition)."""
+    lib = L.lib()
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must be int64 [2, E]")
+    ei = edge_index.contiguous()
+    E, N = int(ei.shape[1]), int(num_nodes)
+    dev = ei.device
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E + N, dtype=torch.int32, device=dev)
+    eperm = torch.empty(E + N, dtype=torch.int32, device=dev) if want_eperm else None
+    e_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    wsb = lib.bgnn_csr_workspace_bytes(N, E)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = lib.bgnn_build_dst_csr(L.ptr(ei) if E > 0 else None, E, N, 1 if rewrite_self_loops else 0, L.ptr(rowptr),
+                                L.ptr(col), L.ptr(eperm), L.ptr(e_out), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_build_dst_csr")
+    ne = int(e_out.item())
+    return DstCSR(rowptr, col[:ne], eperm[:ne] if want_eperm else None, ne, N)
+
+
+def domain_sums(x, mask_u8):
+    """Per-domain column sums + counts as a float64 [2*Din+2] tensor (all-reducible)."""
+    lib = L.lib()
+    N, Din = x.shape
+    sums = torch.zeros(2 * Din + 2, dtype=torch.float64, device=x.device)
+    rc = lib.bgnn_domain_sums_f64(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(sums), L.stream())
+    L.check(rc, "bgnn_domain_sums_f64")
+    return sums
+
+
+def domain_delta(sums, Din):
+    delta = torch.empty(Din, dtype=torch.float32, device=sums.device)
+    rc = L.lib().bgnn_domain_delta_f32(L.ptr(sums), Din, L.ptr(delta), L.stream())
+    L.check(rc, "bgnn_domain_delta_f32")
+    return delta
+
+
+def adaptedconv_transform(x, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s):
+    """-> (h_t2s, h_s2t) as [N, ldh] tensors with ldh = pad4(D); columns >= D are zero."""
+    lib = L.lib()
+    N, Din = x.shape
+    D = W_s.shape[0]
+    ldh = pad4(D)
+    dev = x.device
+    h_t2s = torch.empty(N, ldh, dtype=torch.float32, device=dev)
+    h_s2t = torch.empty(N, ldh, dtype=torch.float32, device=dev)
+    coef = torch.empty(max(N, 1) * 2, dtype=torch.float32, device=dev)
+    rc = lib.bgnn_adaptedconv_transform_f32(
+        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), L.ptr(W_s), L.ptr(b_s), L.ptr(W_t), L.ptr(b_t),
+        L.ptr(g_s2t), L.ptr(g_t2s), D, L.ptr(h_t2s), L.ptr(h_s2t), ldh, L.ptr(coef), L.stream())
+    L.check(rc, "bgnn_adaptedconv_transform_f32")
+    return h_t2s, h_s2t
+
+
+def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
+                          want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None):
+    """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order."""
+    lib = L.lib()
+    n_dst = csr.num_nodes if n_dst is None else int(n_dst)
+    ldh = h_t2s.stride(0)
+    ldo = pad4(D)
+    dev = h_t2s.device
+    if out is None:
+        out = torch.empty(n_dst, ldo, dtype=torch.float32, device=dev)
+    alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
+    rc = lib.bgnn_adaptedconv_aggregate_f32(
+        L.ptr(h_t2s), L.ptr(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
+        L.ptr(mask_u8), n_dst, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
+        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.stream())
+    L.check(rc, "bgnn_adaptedconv_aggregate_f32")
+    return (out, alpha) if want_alpha else out
+
+
+def l2_normalize_rows(q, eps=1e-8):
+    out = torch.empty_like(q)
+    rc = L.lib().bgnn_l2_normalize_rows_f32(L.ptr(q), q.shape[0], q.shape[1], float(eps), L.ptr(out), L.stream())
+    L.check(rc, "bgnn_l2_normalize_rows_f32")
+    return out
+
+
+_COS_D = (32, 64, 128, 256)
+
+
+def _pad_cols(t, d):
+    if t.shape[1] == d:
+        return t.contiguous()
+    out = torch.zeros(t.shape[0], d, dtype=t.dtype, device=t.device)
+    out[:, : t.shape[1]] = t
+    return out
+
+
+def cosine_topk(qn_query, qn_cand, k, apply_sigmoid=True):
+    """Top-k cosine neighbours of every query among the candidates (both already L2-normalised).
+    -> (idx int64 [Nq,k], val fp32 [Nq,k], n_fallback int32[1])."""
+    lib = L.lib()
+    d = qn_query.shape[1]
+    dk = next((c for c in _COS_D if c >= d), None)
+    if dk is None:
+        raise ValueError("embedding width > 256 unsupported")
+    qq, qc = _pad_cols(qn_query, dk), _pad_cols(qn_cand, dk)   # zero columns do not change a dot product
+    Nq, Nc = qq.shape[0], qc.shape[0]
+    dev = qq.device
+    idx = torch.empty(Nq, k, dtype=torch.int64, device=dev)
+    val = torch.empty(Nq, k, dtype=torch.float32, device=dev)
+    nfb = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.bgnn_topk_workspace_bytes(Nq, Nc, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = lib.bgnn_cosine_topk_f32(L.ptr(qq), L.ptr(qc), Nq, Nc, dk, k, 1 if apply_sigmoid else 0, L.ptr(idx),
+                                  L.ptr(val), L.ptr(nfb), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_cosine_topk_f32")
+    return idx, val, nfb
+
+
+def mlp_pair_topk(A_cand, B_query, bn_scale, bn_shift, w2, b2, k, apply_sigmoid=True):
+    lib = L.lib()
+    Nq, Nc, H = B_query.shape[0], A_cand.shape[0], A_cand.shape[1]
+    dev = A_cand.device
+    idx = torch.empty(Nq, k, dtype=torch.int64, device=dev)
+    val = torch.empty(Nq, k, dtype=torch.float32, device=dev)
+    nfb = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.bgnn_topk_workspace_bytes(Nq, Nc, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = lib.bgnn_mlp_pair_topk_f32(L.ptr(A_cand), L.ptr(B_query), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(w2),
+                                    float(b2), Nq, Nc, H, k, 1 if apply_sigmoid else 0, L.ptr(idx), L.ptr(val),
+                                    L.ptr(nfb), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_mlp_pair_topk_f32")
+    return idx, val, nfb
+
+
+def topk_edges(idx, cand_base=0, query_base=0):
+    """[Nq,k] top-k table -> edge_index [2, Nq*k] with (from = candidate, to = query)."""
+    Nq, k = idx.shape
+    out = torch.empty(2, Nq * k, dtype=torch.int64, device=idx.device)
+    rc = L.lib().bgnn_topk_edges_i64(L.ptr(idx), Nq, k, int(cand_base), int(query_base), L.ptr(out), L.stream())
+    L.check(rc, "bgnn_topk_edges_i64")
+    return out
+
+
+def coalesce(edge_index, num_nodes=None):
+    """torch_geometric.utils.coalesce on the GPU (sorted by row*n+col, duplicates dropped)."""
+    lib = L.lib()
+    ei = edge_index.contiguous().clone()
+    E = int(ei.shape[1])
+    if E == 0:
+        return ei
+    n = int(num_nodes) if num_nodes is not None else int(ei.max().item()) + 1
+    dev = ei.device
+    e_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    wsb = lib.bgnn_coalesce_workspace_bytes(E)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = lib.bgnn_coalesce_i64(L.ptr(ei), E, n, L.ptr(e_out), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_coalesce_i64")
+    ne = int(e_out.item())
+    return ei[:, :ne].contiguous()

@@ -1,0 +1,133 @@
+/* bgnn.h -- C ABI of libbgnn_hip.so: the MI355X (gfx950) drop-in for Bridged-GNN's hot path.
+ *
+ * The reference (wendongbi/Bridged-GNN) is pure Python and has NO FFI layer; its "operator
+ * surface" is Python call signatures.  Each entry point below replaces the
+ * third-party/ATen kernels launched by one reference call site; the reference interface it
+ * stands in for is cited as file:line relative to Bridged-GNN/.  bridged_gnn_amd/_lib.py is the
+ * ctypes binding a maintainer would add; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`;
+ *   - nothing is allocated inside; scratch is passed as (ws, ws_bytes) sized by *_workspace_bytes;
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*), reentrant, no globals;
+ *   - return value: 0 = success, <0 = argument error (BGNN_E_*), >0 = hipError_t of a failed launch;
+ *   - row-major, fp32 features, int32 CSR, int64 edge_index ([2,E] contiguous, row 0 = source /
+ *     "from", row 1 = destination / "to" as in torch_geometric).
+ */
+#ifndef BGNN_H_
+#define BGNN_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGNN_VERSION 100
+#define BGNN_E_NULL (-1)        /* required pointer is NULL                     */
+#define BGNN_E_SHAPE (-2)       /* unsupported / inconsistent shape             */
+#define BGNN_E_WORKSPACE (-3)   /* ws_bytes smaller than *_workspace_bytes()    */
+#define BGNN_E_ALIGN (-4)       /* pointer or leading dimension not 16-B aligned */
+#define BGNN_E_RANGE (-5)       /* k / index range not supported                */
+
+int bgnn_version(void);
+const char* bgnn_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * (a10) graph_partition -> by-destination CSR.         models/KTGNN.py:385-398, cached :409-412
+ * Drops self loops and appends one per node (rewrite_self_loops=1, the reference behaviour:
+ * PyG remove_self_loops + add_self_loops), then groups edges by DESTINATION.  Inside a row the
+ * order is input order with the self loop last (stable), so results are run-to-run identical.
+ * The (edge_index1, edge_index2) split of the reference is the per-row domain flag mask[i].
+ * col / eperm need capacity E+N.  *E_out_dev (device int64) receives E' = rowptr[N].
+ * eperm_opt[t] = position of CSR slot t in the rewritten edge list (kept edges in input order,
+ * then the N self loops) -- lets a caller map `alpha` back to the reference's edge order.      */
+size_t bgnn_csr_workspace_bytes(int64_t N, int64_t E);
+int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewrite_self_loops,
+                       int32_t* rowptr, int32_t* col, int32_t* eperm_opt, int64_t* E_out_dev,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a11) AdaptedConv dense part.                                       models/KTGNN.py:275-284
+ * bgnn_domain_sums_f64: per-domain column sums of x ([2*Din] doubles: S then T) and node counts
+ *   ([2] doubles) accumulated into sums_io (caller zeroes it; multi-GPU callers all-reduce it).
+ * bgnn_domain_delta_f32: delta = sums_S/n_S - sums_T/n_T                        (:275)
+ * bgnn_adaptedconv_transform_f32:                                               (:277-284)
+ *   gate_s = tanh(x.g_s2t[:Din] + delta.g_s2t[Din:]),  gate_t likewise with g_t2s
+ *   h_s2t = lin_t(x - gate_s*delta*[i in S]) ; h_t2s = lin_s(x + gate_t*delta*[i in T])
+ *   W_* are [D, Din] row-major (torch Linear.weight), b_* [D] or NULL.  Outputs have leading
+ *   dimension ldh >= D, ldh % 4 == 0; pad columns D..ldh-1 are written as 0.
+ *   The GEMM runs on fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 fmaf chains.
+ * coef_ws: N*2 floats of scratch (per-node gate coefficients).                               */
+int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                         double* sums_io /*[2*Din+2]*/, void* stream);
+int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* delta, void* stream);
+int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                   const uint8_t* mask, const float* delta,
+                                   const float* W_s, const float* b_s, const float* W_t, const float* b_t,
+                                   const float* g_s2t, const float* g_t2s, int32_t D,
+                                   float* h_t2s, float* h_s2t, int64_t ldh,
+                                   float* coef_ws /*[N*2]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
+ *                      models/KTGNN.py:292-305, message :317-319, PyG softmax (call site :299),
+ *                      MessagePassing.propagate(aggr='add') (call sites :303-304)
+ * For destination row i (i < N_dst): H = mask[i] ? h_t2s : h_s2t, a = mask[i] ? a_t2s : a_s2t,
+ *   e_j = a . leaky_relu(H[col_j] + H[i], slope);  alpha = softmax_j(e_j) (+1e-16 in the
+ *   denominator);  out[i] = sum_j alpha_j H[col_j].
+ * One pass over the in-neighbours with an online softmax: every H row is read once per edge.
+ * Feature tables may have more rows than N_dst (multi-GPU: local rows then halo rows).
+ * Optional fused node-wise epilogue of KTGNN_no_complement.forward (:425-430, eval mode):
+ *   out = relu?(out * ep_scale[c] + ep_shift[c])  (BatchNorm1d eval affine; NULL = identity).
+ * alpha_opt ([E'] in CSR order) is optional (tests / backward).
+ * D <= 256; ldh % 4 == 0, ldo % 4 == 0, 16-B aligned tables; pad columns must be zero.        */
+int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                   const float* a_t2s, const float* a_s2t,
+                                   const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                   int64_t N_dst, int32_t D, float negative_slope,
+                                   float* out, int64_t ldo, float* alpha_opt,
+                                   const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a2,a3,a5,a6,a7) kNN bridge: pair scoring + per-query top-k.
+ *     main_bridged_graph.py:45-67 / :90-111 (batched loop), models/models.py:124-130,:944-954
+ *     (scorers), :265-282 (pair_enumeration -- never materialised here), Tensor.topk :60,:104.
+ * Selection rule (declared; replaces torch's unspecified tie order): the k candidates with the
+ * largest CANONICAL score, ties -> lower candidate index; rows come out sorted by that rule.
+ * CANONICAL score = fp64 accumulation in feature-index order of the exact fp32 products
+ * (oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk): pass 1 streams all candidates with fp32
+ * MFMA (cosine) / fp32 VALU (mlp) keeping a k+margin shortlist per query, pass 2 re-scores the
+ * shortlist in canonical arithmetic and proves (by an error-bound margin) that it contains the
+ * exact top-k; rows that cannot be proven are re-done exhaustively (counted in n_fallback_opt).
+ * val_out = sigmoid(score) as fp32 if apply_sigmoid (models.py:129,:953) else the fp32 score.
+ * k <= 56.  q* must already be L2-normalised by bgnn_l2_normalize_rows_f32 (cosine).          */
+int bgnn_l2_normalize_rows_f32(const float* q, int64_t n, int32_t d, float eps, float* out, void* stream);
+size_t bgnn_topk_workspace_bytes(int64_t Nq, int64_t Nc, int32_t k);
+int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand, int64_t Nq, int64_t Nc,
+                         int32_t d, int32_t k, int apply_sigmoid,
+                         int64_t* idx_out /*[Nq,k]*/, float* val_out /*[Nq,k]*/,
+                         int32_t* n_fallback_opt, void* ws, size_t ws_bytes, void* stream);
+int bgnn_mlp_pair_topk_f32(const float* A_cand /*[Nc,H]*/, const float* B_query /*[Nq,H]*/,
+                           const float* bn_scale, const float* bn_shift, const float* w2, float b2,
+                           int64_t Nq, int64_t Nc, int32_t H, int32_t k, int apply_sigmoid,
+                           int64_t* idx_out, float* val_out, int32_t* n_fallback_opt,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* (a2/a3 tail) edge list from the top-k table: edge (from = idx[q,t] + cand_base, to = q + query_base),
+ * main_bridged_graph.py:61-63,:105-107.  edge_index_out is [2, Nq*k].                          */
+int bgnn_topk_edges_i64(const int64_t* idx, int64_t Nq, int32_t k, int64_t cand_base, int64_t query_base,
+                        int64_t* edge_index_out, void* stream);
+
+/* (a8) torch_geometric.utils.coalesce -- call sites main_bridged_graph.py:75,:113,:193.
+ * key = row*num_nodes + col, ascending, duplicates dropped.  In place on [2,E] (row stride E);
+ * the first *E_out_dev columns of each row are valid afterwards.                               */
+size_t bgnn_coalesce_workspace_bytes(int64_t E);
+int bgnn_coalesce_i64(int64_t* edge_index, int64_t E, int64_t num_nodes, int64_t* E_out_dev,
+                      void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGNN_H_ */

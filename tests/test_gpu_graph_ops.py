@@ -1,0 +1,98 @@
+"""GPU: integer edge-list plumbing through the C ABI, bit-exact vs the oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_csr_office_bit_exact(golden):
+    from bridged_gnn_amd import ops
+    g, p = golden("office_a2d_graph.npz"), golden("partition_office.npz")
+    und = p["ei_undirected"].astype(np.int64)
+    csr = ops.build_dst_csr(_t(und), g["x"].shape[0], rewrite_self_loops=True, want_eperm=True)
+    rowptr, col, eperm = O.dst_csr(und, g["central_mask"])
+    assert csr.num_edges == 37522
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+    assert np.array_equal(csr.eperm.cpu().numpy(), eperm)
+
+
+@pytest.mark.parametrize("n,e,seed", [(200, 1500, 1), (1000, 0, 2), (5000, 60000, 3), (1, 3, 4)])
+def test_csr_random_multigraph(n, e, seed):
+    from bridged_gnn_amd import ops, synth
+    ei, mask = synth.random_multigraph(max(n, 2), e, n_isolated=min(7, n // 4), seed=seed) if e else \
+        (np.zeros((2, 0), np.int64), np.arange(n) % 2 == 0)
+    n = mask.shape[0]
+    csr = ops.build_dst_csr(_t(ei), n, rewrite_self_loops=True, want_eperm=True)
+    rowptr, col, eperm = O.dst_csr(ei, mask)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+    assert np.array_equal(csr.eperm.cpu().numpy(), eperm)
+    # rewrite off: self loops kept as ordinary edges, no loops appended
+    csr2 = ops.build_dst_csr(_t(ei), n, rewrite_self_loops=False)
+    assert csr2.num_edges == ei.shape[1]
+    if ei.shape[1]:
+        order = np.argsort(ei[1], kind="stable")
+        assert np.array_equal(csr2.col.cpu().numpy(), ei[0][order].astype(np.int32))
+
+
+def test_coalesce_and_undirected(golden):
+    from bridged_gnn_amd import utils
+    g, p = golden("office_a2d_graph.npz"), golden("partition_office.npz")
+    ei = g["edge_index"].astype(np.int64)
+    und = utils.to_undirected(_t(ei), g["x"].shape[0]).cpu().numpy()
+    assert np.array_equal(und, p["ei_undirected"])
+    rng = np.random.default_rng(0)
+    for n, e in ((50, 400), (100000, 300000), (7, 1)):
+        r = rng.integers(0, n, size=(2, e))
+        got = utils.coalesce(_t(r), num_nodes=n).cpu().numpy()
+        assert np.array_equal(got, O.coalesce(r, n))
+        got2 = utils.coalesce(_t(r)).cpu().numpy()                 # num_nodes inferred = max+1
+        assert np.array_equal(got2, O.coalesce(r))
+    assert utils.coalesce(torch.zeros(2, 0, dtype=torch.int64, device=DEV)).shape == (2, 0)
+
+
+def test_graph_partition_api(golden):
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    g, p = golden("office_a2d_graph.npz"), golden("partition_office.npz")
+    m = KTGNN_no_complement(256, 31, 2, 64, dim_share=256)
+    e1, e2, cat = m.graph_partition(_t(p["ei_undirected"].astype(np.int64)), _t(g["central_mask"]))
+    assert np.array_equal(e1.cpu().numpy(), p["e1"]) and np.array_equal(e2.cpu().numpy(), p["e2"])
+    assert cat.shape[1] == 37522
+
+
+def test_topk_edges_and_merge():
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.bridge import merge_graphs
+    from bridged_gnn_amd.data import Data
+    idx = torch.tensor([[2, 0], [1, 1], [0, 2]], dtype=torch.int64, device=DEV)
+    e = ops.topk_edges(idx).cpu().numpy()
+    assert e.tolist() == [[2, 0, 1, 1, 0, 2], [0, 0, 1, 1, 2, 2]]
+    assert np.array_equal(ops.coalesce(_t(e)).cpu().numpy(), O.topk_edges(idx.cpu().numpy()))
+    ds = Data(x=torch.zeros(3, 2, device=DEV), edge_index=_t(np.array([[0, 1], [1, 2]])), y=torch.tensor([0, -1, 1], device=DEV))
+    dt = Data(x=torch.ones(2, 2, device=DEV), edge_index=_t(np.array([[0], [1]])), y=torch.tensor([1, 0], device=DEV),
+              train_mask=torch.tensor([True, False], device=DEV), val_mask=torch.tensor([False, True], device=DEV),
+              test_mask=torch.tensor([False, False], device=DEV))
+    cross = _t(np.array([[2, 2], [0, 0]]))
+    m = merge_graphs(ds, dt, cross)
+    assert m.edge_index.cpu().tolist() == O.merge_graphs(3, 2, [[0, 1], [1, 2]], [[0], [1]], [[2, 2], [0, 0]]).tolist()
+    assert cross.cpu().tolist() == [[2, 2], [0, 0]]                      # argument untouched
+    assert m.central_mask.cpu().tolist() == [True, True, True, False, False]
+    assert m.train_mask.cpu().tolist() == [True, False, True, True, False]
+    assert m.val_mask.cpu().tolist() == [False, False, False, False, True]
+
+
+def test_cpu_tensors_are_refused():
+    from bridged_gnn_amd import ops, utils
+    with pytest.raises(RuntimeError):
+        ops.build_dst_csr(torch.zeros(2, 3, dtype=torch.int64), 4)
+    with pytest.raises(RuntimeError):
+        utils.coalesce(torch.zeros(2, 3, dtype=torch.int64))

@@ -1,0 +1,159 @@
+"""GPU: half A parity -- scorers + top-k through the C ABI.  Index results must be BIT-EXACT vs the
+oracle's declared rule (canonical fp64 score desc, index asc); probabilities within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, sub
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_l2_normalize_bit_exact():
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((3000, 128)).astype(np.float32)
+    q[5] = 0.0                                      # eps clamp
+    q[6] *= 1e-20
+    got = ops.l2_normalize_rows(_t(q)).cpu().numpy()
+    assert np.array_equal(got, OC.l2_normalize_rows(q))
+
+
+@pytest.mark.parametrize("nq,nc,d,k", [(2000, 20000, 128, 20), (300, 5000, 64, 3), (129, 40000, 128, 20),
+                                        (64, 10, 32, 3), (500, 3000, 128, 50), (77, 9000, 100, 24), (40, 6000, 256, 8)])
+def test_cosine_topk_bit_exact(nq, nc, d, k):
+    from bridged_gnn_amd import ops, synth
+    q = OC.l2_normalize_rows(synth.gaussian_embeddings(nq, d, seed=nq))
+    c = OC.l2_normalize_rows(synth.gaussian_embeddings(nc, d, seed=nc + 1))
+    idx, val, nfb = ops.cosine_topk(_t(q), _t(c), k, apply_sigmoid=False)
+    rv, ri = OC.cosine_topk(q, c, k)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert_close(val.cpu().numpy(), rv, rtol=1e-6, atol_scale=1e-7, what="scores")
+    assert int(nfb.item()) <= max(2, nq // 100)
+
+
+def test_cosine_topk_exact_ties_and_duplicates():
+    """duplicated candidates give exactly equal scores: the lower index must win, everywhere."""
+    from bridged_gnn_amd import ops, synth
+    q = OC.l2_normalize_rows(synth.gaussian_embeddings(200, 128, seed=5))
+    base = OC.l2_normalize_rows(synth.gaussian_embeddings(700, 128, seed=6))
+    c = np.concatenate([base, base[:300], base[100:200], base])       # up to 4 copies
+    idx, val, nfb = ops.cosine_topk(_t(q), _t(c), 20, apply_sigmoid=True)
+    rv, ri = OC.cosine_topk(q, c, 20)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert_close(val.cpu().numpy(), O.sigmoid_f32(rv), rtol=1e-5, atol_scale=1e-6, what="probs")
+    # all-identical candidates: every score ties -> indices 0..k-1; the margin proof must fail -> fallback
+    c2 = np.repeat(base[:1], 500, axis=0)
+    idx2, _, nfb2 = ops.cosine_topk(_t(q), _t(c2), 20)
+    assert np.array_equal(idx2.cpu().numpy(), np.tile(np.arange(20), (200, 1)))
+    assert int(nfb2.item()) == 200
+
+
+def test_cosine_topk_gauss_golden_vs_reference(golden):
+    """reference-produced index sets (Similar_noTrans + torch.topk) on tie-free Gaussian data."""
+    from bridged_gnn_amd import ops, synth
+    f = golden("knn_gauss.npz")
+    ns, nt, d, k = int(f["ns"]), int(f["nt"]), int(f["d"]), int(f["k"])
+    qs = ops.l2_normalize_rows(_t(synth.gaussian_embeddings(ns, d, seed=int(f["seed_src"]))))
+    qt = ops.l2_normalize_rows(_t(synth.gaussian_embeddings(nt, d, seed=int(f["seed_tar"]))))
+    idx, val, _ = ops.cosine_topk(qt, qs, k)
+    mine = np.sort(idx.cpu().numpy(), axis=1)
+    ref = np.sort(f["idx"].astype(np.int64), axis=1)
+    assert (mine != ref).any(axis=1).sum() <= 2          # only fp32-sigmoid boundary ties may differ
+    assert_close(val.cpu().numpy(), -np.sort(-f["e_sim"], axis=1), rtol=1e-5, atol_scale=1e-6, what="e_sim")
+
+
+@pytest.mark.parametrize("tag,kc", [("a2d", 20), ("a2w", 8)])
+def test_office_bridge_from_shipped_ckpt(golden, tag, kc):
+    """BASELINE config 1 through the reference-named entry points, from the shipped checkpoint."""
+    from bridged_gnn_amd.bridge import BridgeScorer, add_topk_sim_cross_domain_edges, add_topk_sim_within_domain_edges
+    from bridged_gnn_amd.data import Data
+    f = golden(f"knn_office_{tag}.npz")
+    sd = {"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sim.").items()}
+    model = BridgeScorer(sd, DEV)
+    assert model.sim_mode == "mlp"
+    ns = int(f["n_src"])
+    y = torch.from_numpy(f["y"].astype(np.int64))
+    ds, dt = Data(x=_t(f["z_src"]), y=y[:ns]), Data(x=_t(f["z_tar"]), y=y[ns:])
+    ei, esim, idx, pcs, pct = add_topk_sim_cross_domain_edges(ds, dt, model, k=kc, z_src=_t(f["z_src"]), z_tar=_t(f["z_tar"]),
+                                                              verbose=False)
+    A, B, scale, shift, w2, b2 = O.mlp_pair_terms(f["z_src"], f["z_tar"], sub(f, "sim."))
+    # (1) per-node terms within 1e-5, then indices bit-exact vs the oracle ON THE SAME A/B
+    gA, gB, gs, gh, gw, gb = model.mlp_terms(_t(f["z_src"]), _t(f["z_tar"]))
+    assert_close(gA.cpu().numpy(), A, what="A") ; assert_close(gB.cpu().numpy(), B, what="B")
+    rv, ri = OC.mlp_topk(gA.cpu().numpy(), gB.cpu().numpy(), gs.cpu().numpy(), gh.cpu().numpy(), gw.cpu().numpy(), gb, kc)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(ei.cpu().numpy(), O.topk_edges(ri))
+    # (2) vs the reference's own output: probabilities, and index sets up to boundary ties
+    assert_close(esim.cpu().numpy(), f["cross_e_sim"], rtol=1e-5, atol_scale=1e-6, what="e_sim")
+    s = O.mlp_scores_canonical(A, B, scale, shift, w2, b2)
+    srt = np.sort(s, axis=1)
+    same = np.array([set(a) == set(b) for a, b in zip(idx.cpu().numpy(), f["cross_idx"])])
+    assert ((srt[:, -kc] - srt[:, -kc - 1])[~same] < 2e-6).all()
+    assert ei.shape == f["cross_edge_index"].shape
+    assert np.array_equal(pcs.argmax(1).cpu().numpy(), f["pred_clf_src"]) and np.array_equal(pct.argmax(1).cpu().numpy(), f["pred_clf_tar"])
+    assert_close(pcs.cpu().numpy()[::16], f["probs_clf_src_rows"], what="probs_clf_src")
+    # (3) within-domain k=3 (self matches kept, Appendix B-3)
+    for dom, z in (("src", f["z_src"]), ("tar", f["z_tar"])):
+        e2, es2, i2 = add_topk_sim_within_domain_edges(Data(x=_t(z)), model, k=3, z=_t(z), verbose=False)
+        gA, gB, *_ = model.mlp_terms(_t(z), _t(z))
+        _, ri = OC.mlp_topk(gA.cpu().numpy(), gB.cpu().numpy(), gs.cpu().numpy(), gh.cpu().numpy(), gw.cpu().numpy(), gb, 3)
+        assert np.array_equal(i2.cpu().numpy(), ri)
+        assert_close(es2.cpu().numpy(), f[f"within_{dom}_e_sim"], rtol=1e-5, atol_scale=1e-6, what=f"within {dom}")
+
+
+def test_cosine_v1_scorer_from_twitter_ckpt(golden):
+    from bridged_gnn_amd.bridge import BridgeScorer
+    f = golden("knn_cosine_v1.npz")
+    sd = {"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sim.").items()}
+    model = BridgeScorer(sd, DEV)
+    assert model.sim_mode == "cosine" and model.version == "v1"
+    q_src, q_tar = model.cosine_q(_t(f["z_src"])), model.cosine_q(_t(f["z_tar"]))
+    assert_close(q_src.cpu().numpy(), f["q_src"], rtol=2e-5, atol_scale=2e-6, what="q_src")
+    assert_close(q_tar.cpu().numpy(), f["q_tar"], rtol=2e-5, atol_scale=2e-6, what="q_tar")
+    idx, probs, _ = model.topk(_t(f["z_src"]), _t(f["z_tar"]), 20)
+    # bit-exact vs the oracle on the GPU's own q (collapsed embeddings: cos in [0.95, 1])
+    from bridged_gnn_amd import ops
+    qs, qt = ops.l2_normalize_rows(q_src).cpu().numpy(), ops.l2_normalize_rows(q_tar).cpu().numpy()
+    rv, ri = OC.cosine_topk(qt, qs, 20)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert_close(probs.cpu().numpy(), f["cross_e_sim"], rtol=1e-5, atol_scale=1e-6, what="e_sim vs reference")
+
+
+def test_pair_probs_reference_shaped_api(golden):
+    from bridged_gnn_amd.bridge import BridgeScorer, pair_enumeration
+    f = golden("knn_office_a2d.npz")
+    sd = {"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sim.").items()}
+    model = BridgeScorer(sd, DEV)
+    ns = 2817
+    pairs = pair_enumeration(torch.arange(ns, device=DEV).unsqueeze(-1), torch.arange(3, device=DEV).unsqueeze(-1)).t()
+    p = model.pair_probs(_t(f["z_src"]), _t(f["z_tar"]), pairs[0], pairs[1]).view(-1, ns)
+    tk = p.topk(20, dim=1)
+    assert_close(tk.values.cpu().numpy(), f["cross_e_sim"][:3], rtol=1e-5, atol_scale=1e-6, what="pair probs")
+
+
+def test_c5_scale_sampled_rows_bit_exact():
+    """BASELINE config 5 at full size (100k x 100k, d=128, k=20): 96 sampled query rows re-done by the
+    CPU oracle must match bit-exactly; all rows must be sorted and in range."""
+    from bridged_gnn_amd import ops, synth
+    q = synth.gaussian_embeddings(100_000, 128, seed=0)
+    c = synth.gaussian_embeddings(100_000, 128, seed=1)
+    qn, cn = ops.l2_normalize_rows(_t(q)), ops.l2_normalize_rows(_t(c))
+    idx, val, nfb = ops.cosine_topk(qn, cn, 20)
+    idx_h, val_h = idx.cpu().numpy(), val.cpu().numpy()
+    assert idx_h.min() >= 0 and idx_h.max() < 100_000
+    assert (np.diff(val_h, axis=1) <= 0).all()
+    assert all(len(set(r)) == 20 for r in idx_h[::997])
+    rows = np.arange(0, 100_000, 1043)[:96]
+    qh, ch = qn.cpu().numpy(), cn.cpu().numpy()
+    assert np.array_equal(qh[rows], OC.l2_normalize_rows(q[rows]))
+    _, ri = OC.cosine_topk(qh[rows], ch, 20)
+    assert np.array_equal(idx_h[rows], ri)
+    assert int(nfb.item()) < 100
