@@ -26,7 +26,8 @@ struct AggParams {
   const int32_t* rowptr;
   const int32_t* col;
   const uint8_t* mask;
-  int64_t n_dst;
+  int64_t row_begin;
+  int64_t row_end;
   int32_t D;
   float slope;
   float* out;
@@ -52,13 +53,13 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   const int f0 = (lg % LF) * 4;          // first feature column of this lane
   const bool fvalid = f0 < p.D;          // pad lanes (LF*4 > ldh) never touch memory
 
-  const int64_t ntiles = (p.n_dst + RPB - 1) / RPB;
+  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
 
   for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
-    const int64_t i = tile * RPB + wave * GPW + g;
-    const bool rvalid = i < p.n_dst;
-    const int64_t ic = rvalid ? i : 0;
+    const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.row_end;
+    const int64_t ic = rvalid ? i : p.row_begin;
     const bool dom_s = p.mask[ic] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
 template <int LF, int EP, int U>
 int launch(const AggParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / (LF * EP));
-  int64_t ntiles = (p.n_dst + RPB - 1) / RPB;
+  int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
   int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;   // multiple of 8 (XCD split), <= 8/CU
   if (grid < 8) grid = 8;
   hipLaunchKernelGGL((agg_kernel<LF, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -193,17 +194,17 @@ int launch(const AggParams& p, hipStream_t st) {
 extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                               const float* a_t2s, const float* a_s2t,
                                               const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
-                                              int64_t N_dst, int32_t D, float negative_slope,
+                                              int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                               float* out, int64_t ldo, float* alpha_opt,
                                               const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                               void* stream) {
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
-  if (N_dst < 0 || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
+  if (row_begin < 0 || row_end < row_begin || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
   if ((ldh & 3) || (ldo & 3) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out))
     return BGNN_E_ALIGN;
   if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
-  if (N_dst == 0) return 0;
-  AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, N_dst, D, negative_slope,
+  if (row_end == row_begin) return 0;
+  AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
               out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu};
   hipStream_t st = (hipStream_t)stream;
   const int nv = (D + 3) / 4;   // float4 slots per row

@@ -112,7 +112,7 @@ class AdaptedConv(nn.Module):
             return g
         return split(self.a_g_s2t.weight), split(self.a_g_t2s.weight)
 
-    def transform(self, x, mask_u8, delta=None, sums=None):
+    def transform(self, x, mask_u8, delta=None, sums=None, out=None):
         """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]."""
         xp = _pad_cols4(x)
         din_pad = xp.shape[1]
@@ -124,7 +124,7 @@ class AdaptedConv(nn.Module):
         W_s, W_t = _pad_cols4(self.lin_s.weight.detach()), _pad_cols4(self.lin_t.weight.detach())
         b_s = self.lin_s.bias.detach() if self.lin_s.bias is not None else None
         b_t = self.lin_t.bias.detach() if self.lin_t.bias is not None else None
-        return ops.adaptedconv_transform(xp, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s)
+        return ops.adaptedconv_transform(xp, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s, out=out)
 
     def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None):
         """KTGNN.py:292-305 (+ optional fused BN-eval/ReLU epilogue)."""

@@ -62,15 +62,21 @@ def domain_delta(sums, Din):
     return delta
 
 
-def adaptedconv_transform(x, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s):
-    """-> (h_t2s, h_s2t) as [N, ldh] tensors with ldh = pad4(D); columns >= D are zero."""
+def adaptedconv_transform(x, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s, out=None):
+    """-> (h_t2s, h_s2t) as [N, ldh] tensors with ldh = pad4(D); columns >= D are zero.
+    `out=(h_t2s, h_s2t)` may pass larger preallocated tables (>= N rows, stride ldh): the first N rows
+    are written (multi-GPU: halo rows follow)."""
     lib = L.lib()
     N, Din = x.shape
     D = W_s.shape[0]
     ldh = pad4(D)
     dev = x.device
-    h_t2s = torch.empty(N, ldh, dtype=torch.float32, device=dev)
-    h_s2t = torch.empty(N, ldh, dtype=torch.float32, device=dev)
+    if out is None:
+        h_t2s = torch.empty(N, ldh, dtype=torch.float32, device=dev)
+        h_s2t = torch.empty(N, ldh, dtype=torch.float32, device=dev)
+    else:
+        h_t2s, h_s2t = out
+        assert h_t2s.shape[0] >= N and h_s2t.shape[0] >= N and h_t2s.stride(0) == ldh and h_s2t.stride(0) == ldh
     coef = torch.empty(max(N, 1) * 2, dtype=torch.float32, device=dev)
     rc = lib.bgnn_adaptedconv_transform_f32(
         L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), L.ptr(W_s), L.ptr(b_s), L.ptr(W_t), L.ptr(b_t),
@@ -80,10 +86,13 @@ def adaptedconv_transform(x, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s):
 
 
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
-                          want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None):
-    """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order."""
+                          want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
+                          row_begin=0, row_end=None):
+    """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order.
+    Only rows [row_begin, row_end) are computed (default: all n_dst rows)."""
     lib = L.lib()
     n_dst = csr.num_nodes if n_dst is None else int(n_dst)
+    row_end = n_dst if row_end is None else int(row_end)
     ldh = h_t2s.stride(0)
     ldo = pad4(D)
     dev = h_t2s.device
@@ -92,7 +101,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr(h_t2s), L.ptr(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
-        L.ptr(mask_u8), n_dst, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
+        L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
         L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out

@@ -73,11 +73,13 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
  * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
  *                      models/KTGNN.py:292-305, message :317-319, PyG softmax (call site :299),
  *                      MessagePassing.propagate(aggr='add') (call sites :303-304)
- * For destination row i (i < N_dst): H = mask[i] ? h_t2s : h_s2t, a = mask[i] ? a_t2s : a_s2t,
+ * For destination row i (row_begin <= i < row_end; rowptr/mask/out/H are indexed by the absolute
+ * row so a caller can aggregate interior rows while a halo exchange for the boundary rows is in
+ * flight): H = mask[i] ? h_t2s : h_s2t, a = mask[i] ? a_t2s : a_s2t,
  *   e_j = a . leaky_relu(H[col_j] + H[i], slope);  alpha = softmax_j(e_j) (+1e-16 in the
  *   denominator);  out[i] = sum_j alpha_j H[col_j].
  * One pass over the in-neighbours with an online softmax: every H row is read once per edge.
- * Feature tables may have more rows than N_dst (multi-GPU: local rows then halo rows).
+ * Feature tables may have more rows than row_end (multi-GPU: local rows then halo rows).
  * Optional fused node-wise epilogue of KTGNN_no_complement.forward (:425-430, eval mode):
  *   out = relu?(out * ep_scale[c] + ep_shift[c])  (BatchNorm1d eval affine; NULL = identity).
  * alpha_opt ([E'] in CSR order) is optional (tests / backward).
@@ -85,7 +87,7 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
 int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                    const float* a_t2s, const float* a_s2t,
                                    const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
-                                   int64_t N_dst, int32_t D, float negative_slope,
+                                   int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                    float* out, int64_t ldo, float* alpha_opt,
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                    void* stream);

@@ -1,0 +1,104 @@
+"""GPU: the partitioned driver's device pieces (row-range aggregation over local+halo tables, transform
+into oversized tables, world=1 PartitionedKTGNN).  RCCL itself needs >1 GPU (driver-side scaling run);
+here the exchange is simulated in-process by copying rows exactly as all_to_all_single would deliver them."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _model(feat, hidden, classes):
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    torch.manual_seed(0)
+    m = KTGNN_no_complement(feat, classes, 2, hidden, use_bn=True, dim_share=feat)
+    g = torch.Generator().manual_seed(3)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+    return m.to(DEV).eval()
+
+
+def test_partitioned_world1_equals_plain_forward():
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.dist import PartitionedKTGNN
+    ei, mask = synth.bridged_graph(3000, 2000, 4, 8, 6000, cluster=128, seed=4)
+    x = torch.randn(5000, 64, device=DEV)
+    m = _model(64, 64, 3)
+    with torch.no_grad():
+        ref = m(Data(x=x, edge_index=_t(ei), central_mask=_t(mask)))[:3]
+    pk = PartitionedKTGNN(m, ei, mask, 0, 1, DEV)
+    out = pk.forward(x[pk.owned_global])
+    inv = torch.empty_like(pk.owned_global)
+    inv[pk.owned_global] = torch.arange(5000, device=DEV)
+    for a, b in zip(out, ref):
+        assert torch.allclose(a[inv], b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_simulated_multi_rank_conv_matches_single_gpu(world):
+    """every rank's (transform -> exchanged halo -> interior/boundary aggregation) reproduces the
+    single-GPU AdaptedConv output row for row."""
+    from bridged_gnn_amd import ops, synth
+    from bridged_gnn_amd.dist import PartitionPlan
+    from bridged_gnn_amd.ktgnn import AdaptedConv, _pad_cols4
+    n_src, n_tar, din, D = 4000, 3000, 32, 64
+    ei, mask = synth.bridged_graph(n_src, n_tar, 4, 8, 9000, cluster=128, p_local=0.8, seed=world)
+    n = n_src + n_tar
+    x = torch.randn(n, din, device=DEV)
+    torch.manual_seed(1)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV).eval()
+    with torch.no_grad():
+        csr = ops.build_dst_csr(_t(ei), n)
+        ref = conv(x, None, central_mask=_t(mask), csr=csr)
+    plans = [PartitionPlan(ei, mask, r, world) for r in range(world)]
+    # (1) sums: sum over ranks of local sums == global sums (the all-reduce)
+    locs = []
+    for p in plans:
+        og = _t(p.owned_global)
+        locs.append(ops.domain_sums(_pad_cols4(x[og]), _t(p.mask_local).to(torch.uint8)))
+    sums = torch.stack(locs).sum(0)
+    delta = ops.domain_delta(sums, din)
+    # (2) per-rank transform straight into [local + halo] tables
+    tabs = []
+    for p in plans:
+        og = _t(p.owned_global)
+        ld = ops.pad4(D)
+        ht2s = torch.zeros(p.n_local + p.n_halo[0], ld, device=DEV)
+        hs2t = torch.zeros(p.n_local + p.n_halo[1], ld, device=DEV)
+        with torch.no_grad():
+            conv.transform(x[og].contiguous(), _t(p.mask_local).to(torch.uint8), delta=delta, out=(ht2s, hs2t))
+        tabs.append((ht2s, hs2t))
+    # (3) simulated all_to_all_single: receiver r gets, peer by peer, what q's send list holds for r
+    for r, p in enumerate(plans):
+        for t in (0, 1):
+            off = p.n_local
+            for q, pq in enumerate(plans):
+                s0 = sum(pq.send_splits[t][:r])
+                rows = pq.send_rows[t][s0: s0 + pq.send_splits[t][r]]
+                if len(rows):
+                    tabs[r][t][off: off + len(rows)] = tabs[q][t][_t(rows)]
+                off += len(rows)
+    # (4) interior then boundary aggregation per rank
+    got = torch.zeros_like(ref)
+    a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
+    a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
+    for r, p in enumerate(plans):
+        lcsr = ops.DstCSR(_t(p.rowptr), _t(p.col), None, p.local_num_edges, p.n_local)
+        m8 = _t(p.mask_local).to(torch.uint8)
+        out = torch.full((p.n_local, ops.pad4(D)), float("nan"), device=DEV)
+        ops.adaptedconv_aggregate(tabs[r][0], tabs[r][1], a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
+                                  row_begin=0, row_end=p.n_interior)
+        assert torch.isnan(out[p.n_interior:]).all() or p.n_interior == p.n_local     # only the range was written
+        ops.adaptedconv_aggregate(tabs[r][0], tabs[r][1], a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
+                                  row_begin=p.n_interior, row_end=p.n_local)
+        got[_t(p.owned_global)] = out[:, :D]
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+    assert sum(p.n_halo[0] + p.n_halo[1] for p in plans) > 0
