@@ -120,11 +120,27 @@ def load_bridged_graph(path, map_location="cpu"):
 
 def save_bridged_graph(data, path):
     """Write `data` in the reference's on-disk layout (Data -> _store -> _mapping) so that both
-    `load_bridged_graph` and a PyG-2.x `torch.load` can read it (main_bridged_graph.py:317-320)."""
+    `load_bridged_graph` and a PyG-2.x `torch.load` can read it (main_bridged_graph.py:317-320).
+    pickle refers to classes by module path, so while writing (only) the two stand-ins are made
+    resolvable under PyG's module names unless the real torch_geometric is importable."""
+    import sys
+    import types
     store = _PygGlobalStorage()
     d = _PygData()
     store.__dict__["_mapping"] = {k: getattr(data, k).detach().cpu() if torch.is_tensor(getattr(data, k))
                                   else getattr(data, k) for k in data.keys}
     store.__dict__["_parent"] = None
     d.__dict__["_store"] = store
-    torch.save(d, path)
+    injected = []
+    try:
+        for modname, cls in (("torch_geometric", None), ("torch_geometric.data", None),
+                             ("torch_geometric.data.data", _PygData), ("torch_geometric.data.storage", _PygGlobalStorage)):
+            if modname not in sys.modules:
+                sys.modules[modname] = types.ModuleType(modname)
+                injected.append(modname)
+            if cls is not None and not hasattr(sys.modules[modname], cls.__name__):
+                setattr(sys.modules[modname], cls.__name__, cls)
+        torch.save(d, path)
+    finally:
+        for modname in injected:
+            sys.modules.pop(modname, None)
