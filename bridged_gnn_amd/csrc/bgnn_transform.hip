@@ -6,43 +6,71 @@
 //   h_s2t_i = W_t (x_i - gate_s delta [i in S]) + b_t                                       (:279,:283)
 //   h_t2s_i = W_s (x_i + gate_t delta [i in T]) + b_s                                       (:280,:284)
 //
-// The shifted inputs differ from x by a per-row scalar times delta, so the GEMM applies the shift as
-// an A-operand transform while staging x through LDS (x is read from HBM once per output matrix,
-// the [N,Din] shifted copies the reference materialises never exist).  The contraction itself is
-// the only MFMA work on path B: v_mfma_f32_32x32x2_f32, exact-fp32 fmaf chains.
+// The shifted inputs differ from x by a per-row scalar times delta, so by linearity
+//   h_s2t_i = W_t x_i + b_t - [i in S] gate_s (W_t delta),  h_t2s_i = W_s x_i + b_s + [i in T] gate_t (W_s delta):
+// ONE pass over x feeds a GEMM against the packed rows [W_t ; W_s] of up to two convs that share the
+// input (clf_base / clf_target), the two gate GEMVs ride in the A-staging loads, and the rank-1 shift
+// is applied in the epilogue.  x is read from HBM once, the [N,Din] shifted copies and the gate
+// vector the reference materialises never exist.  The contraction is the only MFMA work on path B:
+// v_mfma_f32_32x32x2_f32, exact-fp32 fmaf chains.
 #include "bgnn_common.h"
 
 namespace {
 
 // ------------------------------------------------------------------ per-domain column sums (fp64)
+// thread = (column float4 lane, row lane); 4 rows in flight per thread; block partials via LDS, one
+// fp64 atomic per (block, column, domain).
 __global__ __launch_bounds__(256) void domain_sums_kernel(const float* __restrict__ x, int64_t N, int32_t Din,
                                                           int64_t ldx, const uint8_t* __restrict__ mask,
                                                           double* __restrict__ sums) {
-  // thread layout: cw column lanes x rl row lanes
-  const int cw = Din < 256 ? Din : 256;
-  const int rl = 256 / cw;
+  const int nc4 = Din >> 2;                       // Din % 4 == 0
+  const int cw = nc4 < 256 ? nc4 : 256;           // column lanes
+  const int rl = 256 / cw;                        // row lanes
   const int tid = threadIdx.x;
   const int cl = tid % cw, r0 = tid / cw;
   const bool active = r0 < rl;
   const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const int64_t rb = blockIdx.x * rows_per_block;
   const int64_t re = min(rb + rows_per_block, N);
-  extern __shared__ double sh[];   // [rl][2][cw]
-  for (int cb = 0; cb < Din; cb += cw) {          // block-uniform trip count (barriers inside)
-    const int c = cb + cl;
-    const bool cok = active && c < Din;
-    double as = 0.0, at = 0.0;
-    if (cok)
-      for (int64_t r = rb + r0; r < re; r += rl) {
-        const double v = (double)x[r * ldx + c];
-        if (mask[r]) as += v; else at += v;
+  extern __shared__ double sh[];                  // [rl][2][cw][4]
+  for (int cb = 0; cb < nc4; cb += cw) {          // block-uniform trip count (barriers inside)
+    const int c4 = cb + cl;
+    const bool cok = active && c4 < nc4;
+    double as[4] = {0, 0, 0, 0}, at[4] = {0, 0, 0, 0};
+    if (cok) {
+      int64_t r = rb + r0;
+      for (; r + 3 * rl < re; r += 4 * rl) {
+        float4 v[4];
+        bool m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = *reinterpret_cast<const float4*>(x + (r + u * rl) * ldx + c4 * 4);
+          m[u] = mask[r + u * rl] != 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double a = v[u].x, b = v[u].y, c = v[u].z, d = v[u].w;
+          if (m[u]) { as[0] += a; as[1] += b; as[2] += c; as[3] += d; }
+          else      { at[0] += a; at[1] += b; at[2] += c; at[3] += d; }
+        }
       }
-    if (active) { sh[(r0 * 2 + 0) * cw + cl] = as; sh[(r0 * 2 + 1) * cw + cl] = at; }
+      for (; r < re; r += rl) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+        if (mask[r]) { as[0] += v.x; as[1] += v.y; as[2] += v.z; as[3] += v.w; }
+        else         { at[0] += v.x; at[1] += v.y; at[2] += v.z; at[3] += v.w; }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sh[((r0 * 2 + 0) * cw + cl) * 4 + e] = as[e]; sh[((r0 * 2 + 1) * cw + cl) * 4 + e] = at[e]; }
+    }
     __syncthreads();
     if (cok && r0 == 0) {
-      for (int q = 1; q < rl; ++q) { as += sh[(q * 2 + 0) * cw + cl]; at += sh[(q * 2 + 1) * cw + cl]; }
-      atomicAdd(&sums[c], as);
-      atomicAdd(&sums[Din + c], at);
+      for (int q = 1; q < rl; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { as[e] += sh[((q * 2 + 0) * cw + cl) * 4 + e]; at[e] += sh[((q * 2 + 1) * cw + cl) * 4 + e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(&sums[c4 * 4 + e], as[e]); atomicAdd(&sums[Din + c4 * 4 + e], at[e]); }
     }
     __syncthreads();
   }
@@ -65,169 +93,186 @@ __global__ void domain_delta_kernel(const double* __restrict__ sums, int32_t Din
   delta[c] = ms - mt;
 }
 
-// ------------------------------------------------------------------ gates -> per-row shift coefficients
-// coef[i] = (-gate_s * [i in S], +gate_t * [i in T])
-template <int LF>
-__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, int64_t N, int32_t Din, int64_t ldx,
-                                                   const uint8_t* __restrict__ mask, const float* __restrict__ delta,
-                                                   const float* __restrict__ g_s2t, const float* __restrict__ g_t2s,
-                                                   float* __restrict__ coef) {
-  constexpr int RPW = 64 / LF;
-  __shared__ float cst[2];
+// ------------------------------------------------------------------ W.delta and gate constants
+// wd[j] = Wp[j] . delta (j < NC) ; gc[h*2+t] = g[h][t][Din:] . delta
+__global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, int32_t NC, int32_t Din,
+                                                 const float* __restrict__ delta, const float* __restrict__ g,
+                                                 int32_t n_heads, float* __restrict__ wd, float* __restrict__ gc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) {   // constant half of the GEMV: delta . g[Din:]
-    float cs = 0.f, ct = 0.f;
-    for (int c = lane; c < Din; c += 64) { cs = fmaf(delta[c], g_s2t[Din + c], cs); ct = fmaf(delta[c], g_t2s[Din + c], ct); }
-    cs = bgnn::group_sum<64>(cs);
-    ct = bgnn::group_sum<64>(ct);
-    if (lane == 0) { cst[0] = cs; cst[1] = ct; }
-  }
-  __syncthreads();
-  const float cs = cst[0], ct = cst[1];
-  const int g = lane / LF, l = lane % LF;
-  const int64_t nrt = (N + 4 * RPW - 1) / (4 * RPW);
-  for (int64_t t = blockIdx.x; t < nrt; t += gridDim.x) {
-    const int64_t i = t * (4 * RPW) + wave * RPW + g;
-    const bool ok = i < N;
-    float ds = 0.f, dt = 0.f;
-    if (ok)
-      for (int c = l * 4; c < Din; c += LF * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(x + i * ldx + c);
-        const float4 a = *reinterpret_cast<const float4*>(g_s2t + c);
-        const float4 b = *reinterpret_cast<const float4*>(g_t2s + c);
-        ds = fmaf(v.x, a.x, ds); ds = fmaf(v.y, a.y, ds); ds = fmaf(v.z, a.z, ds); ds = fmaf(v.w, a.w, ds);
-        dt = fmaf(v.x, b.x, dt); dt = fmaf(v.y, b.y, dt); dt = fmaf(v.z, b.z, dt); dt = fmaf(v.w, b.w, dt);
-      }
-    ds = bgnn::group_sum<LF>(ds);
-    dt = bgnn::group_sum<LF>(dt);
-    if (ok && l == 0) {
-      const bool s = mask[i] != 0;
-      float2 o;
-      o.x = s ? -tanhf(ds + cs) : 0.f;
-      o.y = s ? 0.f : tanhf(dt + ct);
-      *reinterpret_cast<float2*>(coef + i * 2) = o;
-    }
+  const int nrows = NC + 2 * n_heads;
+  for (int j = blockIdx.x * 4 + wave; j < nrows; j += gridDim.x * 4) {
+    const float* row = j < NC ? Wp + (int64_t)j * Din : g + (int64_t)(j - NC) * 2 * Din + Din;
+    float acc = 0.f;
+    for (int c = lane; c < Din; c += 64) acc = fmaf(row[c], delta[c], acc);
+    acc = bgnn::group_sum<64>(acc);
+    if (lane == 0) { if (j < NC) wd[j] = acc; else gc[j - NC] = acc; }
   }
 }
 
-// ------------------------------------------------------------------ MFMA fp32 GEMM with shift prologue
+// ------------------------------------------------------------------ fused MFMA fp32 GEMM
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BK = 32, LDS_LD = BK + 4;   // +4 floats: conflict-free ds_read_b128 (16-lane groups)
+constexpr int MAXH = 2;
 
 struct GemmParams {
   const float* x; int64_t ldx; int64_t N; int32_t Din;
-  const float* coef; const float* delta;
-  const float* W[2]; const float* b[2];   // [0] = lin_t -> h_s2t, [1] = lin_s -> h_t2s
-  float* out[2]; int64_t ldh; int32_t D;
+  const uint8_t* mask;
+  const float* Wp;      // [NC, Din] packed: per head, ldh rows of W_t (zero padded) then ldh rows of W_s
+  const float* bias;    // [NC]
+  const float* wd;      // [NC]   Wp . delta
+  const float* g;       // [n_heads][2][2*Din]  gate vectors (s2t, t2s), x-half first
+  const float* gc;      // [n_heads][2]         delta-half constants
+  float* out[MAXH][2];  // [head][table]  table 0 = h_s2t (W_t), 1 = h_t2s (W_s)
+  int64_t ldh; int32_t NC; int32_t n_heads;
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile layout");
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
-  const int which = blockIdx.z;
-  const float* __restrict__ W = p.W[which];
-  const float* __restrict__ bias = p.b[which];
-  float* __restrict__ out = p.out[which];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+  __shared__ float coef[BM][MAXH][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
-  const int col0 = blockIdx.y * BN;
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch) -> give them the SAME
+  // row tile and adjacent column tiles so the second read of the x tile hits that XCD's L2.
+  const int nct = (p.NC + BN - 1) / BN;
+  const int64_t b = blockIdx.x;
+  const int64_t grp = b / (8 * nct), within = b % (8 * nct);
+  const int64_t rt = grp * 8 + (within & 7);
+  const int ct = (int)(within >> 3);
+  const int64_t row0 = rt * BM;
+  const int col0 = ct * BN;
+  if (row0 >= p.N) return;                       // block-uniform
 
   // staging assignment: 8 threads cover one 32-float row segment, 32 rows per pass
   const int sr = tid >> 3, sc = (tid & 7) * 4;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
-  float cf[APASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) {
-    const int64_t r = row0 + sr + 32 * j;
-    cf[j] = r < p.N ? p.coef[r * 2 + which] : 0.f;
-  }
   float4 ra[APASS], rb[BPASS];
+  float gd[APASS][MAXH][2];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j)
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) gd[j][h][0] = gd[j][h][1] = 0.f;
+
   auto gload = [&](int k0) {
     const int k = k0 + sc;
     const bool kok = k < p.Din;   // Din % 4 == 0 -> a float4 is entirely in or out
-    float4 d4 = kok ? *reinterpret_cast<const float4*>(p.delta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g4[MAXH][2];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        g4[h][t] = (kok && h < p.n_heads) ? *reinterpret_cast<const float4*>(p.g + ((int64_t)(h * 2 + t) * 2) * p.Din + k)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int64_t r = row0 + sr + 32 * j;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && r < p.N) {
-        v = *reinterpret_cast<const float4*>(p.x + r * p.ldx + k);
-        // x -/+ gate * delta * [domain]  (KTGNN.py:279-280); same op order as the reference: (gate*delta) then add
-        v.x += cf[j] * d4.x; v.y += cf[j] * d4.y; v.z += cf[j] * d4.z; v.w += cf[j] * d4.w;
-      }
+      if (kok && r < p.N) v = *reinterpret_cast<const float4*>(p.x + r * p.ldx + k);
       ra[j] = v;
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float a = gd[j][h][t];
+          a = fmaf(v.x, g4[h][t].x, a); a = fmaf(v.y, g4[h][t].y, a);
+          a = fmaf(v.z, g4[h][t].z, a); a = fmaf(v.w, g4[h][t].w, a);
+          gd[j][h][t] = a;
+        }
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int n = col0 + sr + 32 * j;
-      rb[j] = (kok && n < p.D) ? *reinterpret_cast<const float4*>(W + (int64_t)n * p.Din + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[j] = (kok && n < p.NC) ? *reinterpret_cast<const float4*>(p.Wp + (int64_t)n * p.Din + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(&As[(sr + 32 * j) * LDS_LD + sc]) = ra[j];
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(&As[buf][(sr + 32 * j) * LDS_LD + sc]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(&Bs[(sr + 32 * j) * LDS_LD + sc]) = rb[j];
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(&Bs[buf][(sr + 32 * j) * LDS_LD + sc]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int c = 0; c < TN; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
   const int nk = (p.Din + BK - 1) / BK;
   gload(0);
-  sstore();
+  sstore(0);
+  if (nk > 1) gload(BK);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const int cur = kt & 1;
+    if (kt + 1 < nk) sstore(cur ^ 1);            // tile kt+1 (in registers since the previous compute phase)
+    if (kt + 2 < nk) gload((kt + 2) * BK);       // tile kt+2 flies during this compute phase
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        af[a] = *reinterpret_cast<const float4*>(&As[((wm * TM + a) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
+        af[a] = *reinterpret_cast<const float4*>(&As[cur][((wm * TM + a) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
-        bf[b] = *reinterpret_cast<const float4*>(&Bs[((wn * TN + b) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
+      for (int c = 0; c < TN; ++c)
+        bf[c] = *reinterpret_cast<const float4*>(&Bs[cur][((wn * TN + c) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
+        for (int c = 0; c < TN; ++c) {
           // lanes 0-31 carry k = 8kb+s, lanes 32-63 carry k = 8kb+4+s (same permutation for A and B)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[c].x, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[c].y, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[c].z, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[c].w, acc[a][c], 0, 0, 0);
         }
     }
     __syncthreads();
-    if (kt + 1 < nk) {
-      sstore();
-      __syncthreads();
-    }
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // gates -> per-row rank-1 coefficients (KTGNN.py:277-280): coef[row][h] = (-gate_s [i in S], +gate_t [i in T])
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int c = col0 + (wn * TN + b) * 32 + fr;
-    const float bv = (bias != nullptr && c < p.D) ? bias[c] : 0.f;
+  for (int j = 0; j < APASS; ++j) {
+    const int64_t r = row0 + sr + 32 * j;
+    const bool s = r < p.N ? (p.mask[r] != 0) : false;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (row < p.N && c < p.ldh) out[row * p.ldh + c] = acc[a][b][r] + bv;
+    for (int h = 0; h < MAXH; ++h) {
+      const float ds = bgnn::group_sum<8>(gd[j][h][0]);
+      const float dt = bgnn::group_sum<8>(gd[j][h][1]);
+      if ((tid & 7) == 0 && h < p.n_heads) {
+        coef[sr + 32 * j][h][0] = s ? -tanhf(ds + p.gc[h * 2 + 0]) : 0.f;
+        coef[sr + 32 * j][h][1] = s ? 0.f : tanhf(dt + p.gc[h * 2 + 1]);
       }
+    }
+  }
+  __syncthreads();
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int ld2 = 2 * (int)p.ldh;
+#pragma unroll
+  for (int c = 0; c < TN; ++c) {
+    const int col = col0 + (wn * TN + c) * 32 + fr;
+    if (col < p.NC) {
+      const int h = col / ld2, rem = col % ld2;
+      const int t = rem >= p.ldh ? 1 : 0;
+      const int cc = rem - t * (int)p.ldh;
+      const float bv = p.bias[col], wv = p.wd[col];
+      float* __restrict__ out = p.out[h][t];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int64_t row = row0 + lr;
+          if (row < p.N) out[row * p.ldh + cc] = fmaf(coef[lr][h][t], wv, acc[a][c][r] + bv);
+        }
+    }
   }
 }
 
@@ -236,12 +281,13 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
 extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
                                     double* sums_io, void* stream) {
   if (!x || !mask || !sums_io) return BGNN_E_NULL;
-  if (N < 0 || Din <= 0 || ldx < Din) return BGNN_E_SHAPE;
+  if (N < 0 || Din <= 0 || ldx < Din || (Din & 3) || (ldx & 3)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(x)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
-  const int cw = Din < 256 ? Din : 256, rl = 256 / cw;
-  int64_t grid = (N + 255) / 256;
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(256), sizeof(double) * rl * 2 * cw,
+  const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = 256 / cw;
+  int64_t grid = (N + 63) / 64;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(256), sizeof(double) * rl * 2 * cw * 4,
                      (hipStream_t)stream, x, N, Din, ldx, mask, sums_io);
   BGNN_LAUNCH_CHECK();
   return 0;
@@ -257,45 +303,36 @@ extern "C" int bgnn_domain_delta_f32(const double* sums, int32_t Din, float* del
 
 extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                               const uint8_t* mask, const float* delta,
-                                              const float* W_s, const float* b_s, const float* W_t, const float* b_t,
-                                              const float* g_s2t, const float* g_t2s, int32_t D,
-                                              float* h_t2s, float* h_s2t, int64_t ldh,
-                                              float* coef_ws, void* stream) {
-  if (!x || !mask || !delta || !W_s || !W_t || !g_s2t || !g_t2s || !h_t2s || !h_s2t || !coef_ws) return BGNN_E_NULL;
+                                              int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                              const float* gates,
+                                              float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                              int64_t ldh, float* small_ws, void* stream) {
+  if (!x || !mask || !delta || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
+  if (n_heads < 1 || n_heads > MAXH || (n_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
   if (N < 0 || Din <= 0 || D <= 0 || ldx < Din || ldh < D) return BGNN_E_SHAPE;
   if ((Din & 3) || (ldx & 3) || (ldh & 3)) return BGNN_E_SHAPE;
-  if (!bgnn_aligned16(x) || !bgnn_aligned16(W_s) || !bgnn_aligned16(W_t) || !bgnn_aligned16(delta) ||
-      !bgnn_aligned16(g_s2t) || !bgnn_aligned16(g_t2s) || !bgnn_aligned16(coef_ws))
-    return BGNN_E_ALIGN;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(Wp) || !bgnn_aligned16(delta) || !bgnn_aligned16(gates)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int nv = Din / 4;
-    int64_t grid = 2048;
-#define GATE(LF)                                                                                          \
-  {                                                                                                       \
-    int64_t nrt = (N + 4 * (64 / LF) - 1) / (4 * (64 / LF));                                              \
-    if (nrt < grid) grid = nrt;                                                                           \
-    hipLaunchKernelGGL((gate_kernel<LF>), dim3((unsigned)grid), dim3(256), 0, st, x, N, Din, ldx, mask,   \
-                       delta, g_s2t, g_t2s, coef_ws);                                                     \
-  }
-    if (nv <= 8) GATE(8) else if (nv <= 16) GATE(16) else if (nv <= 32) GATE(32) else GATE(64)
-#undef GATE
-    BGNN_LAUNCH_CHECK();
-  }
+  const int NC = n_heads * 2 * (int)ldh;
+  float* wd = small_ws;            // [NC]
+  float* gc = small_ws + NC;       // [n_heads*2]
+  hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((NC + 2 * n_heads + 3) / 4)), dim3(256), 0, st, Wp, NC, Din, delta, gates,
+                     n_heads, wd, gc);
+  BGNN_LAUNCH_CHECK();
   GemmParams p;
-  p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.coef = coef_ws; p.delta = delta;
-  p.W[0] = W_t; p.b[0] = b_t; p.out[0] = h_s2t;
-  p.W[1] = W_s; p.b[1] = b_s; p.out[1] = h_t2s;
-  p.ldh = ldh; p.D = D;
-  const unsigned gx = (unsigned)((N + BM - 1) / BM);
-  // ldh columns are produced (pad columns come out as exact zeros: zero weight rows, no bias)
-  if (ldh <= 32) {
-    hipLaunchKernelGGL((transform_gemm_kernel<32, 4, 1, 1, 1>), dim3(gx, 1, 2), dim3(256), 0, st, p);
-  } else if (ldh <= 64) {
-    hipLaunchKernelGGL((transform_gemm_kernel<64, 2, 2, 2, 1>), dim3(gx, 1, 2), dim3(256), 0, st, p);
+  p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;
+  p.out[0][0] = h_s2t_0; p.out[0][1] = h_t2s_0; p.out[1][0] = h_s2t_1; p.out[1][1] = h_t2s_1;
+  p.ldh = ldh; p.NC = NC; p.n_heads = n_heads;
+  const int64_t nrt = (N + BM - 1) / BM;
+  const int64_t nrt8 = (nrt + 7) / 8 * 8;        // row tiles rounded up to the XCD group size
+  if (NC <= 32) {
+    hipLaunchKernelGGL((transform_gemm_kernel<32, 4, 1, 1, 1>), dim3((unsigned)nrt8), dim3(256), 0, st, p);
+  } else if (NC <= 64) {
+    hipLaunchKernelGGL((transform_gemm_kernel<64, 2, 2, 2, 1>), dim3((unsigned)nrt8), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL((transform_gemm_kernel<128, 2, 2, 2, 2>), dim3(gx, (unsigned)((ldh + 127) / 128), 2), dim3(256), 0, st, p);
+    const int nct = (NC + 127) / 128;
+    hipLaunchKernelGGL((transform_gemm_kernel<128, 2, 2, 2, 2>), dim3((unsigned)(nrt8 * nct)), dim3(256), 0, st, p);
   }
   BGNN_LAUNCH_CHECK();
   return 0;

@@ -184,7 +184,7 @@ class PartitionedKTGNN:
         # local rows followed by halo rows in one allocation per table; the transform writes the local part
         h_t2s = torch.empty(p.n_local + p.n_halo[0], ld, dtype=torch.float32, device=self.device)
         h_s2t = torch.empty(p.n_local + p.n_halo[1], ld, dtype=torch.float32, device=self.device)
-        conv.transform(x, self.mask_u8, delta=delta, out=(h_t2s, h_s2t))
+        conv.transform(x, self.mask_u8, delta=delta, out=(h_t2s, h_s2t))   # writes rows [0, n_local)
         self.halo.start((h_t2s, h_s2t))
         a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
         a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
@@ -219,6 +219,6 @@ class PartitionedKTGNN:
                 x = F.relu(x)
             x = x.contiguous()
         base, sums = self._conv(m.clf_base, x)
-        hat, _ = self._conv(m.clf_target, m.clf_transformer(x).contiguous())
+        hat, _ = self._conv(m.clf_target, m._transformer_eval(x).contiguous())
         targ, _ = self._conv(m.clf_target, x, sums=sums)
         return F.log_softmax(base, dim=1), F.log_softmax(targ, dim=1), F.log_softmax(hat, dim=1)

@@ -100,31 +100,37 @@ class AdaptedConv(nn.Module):
             self.lin_r.reset_parameters()
 
     # -- pieces (also used by the multi-GPU driver in dist.py) ---------------------------------
-    def gate_vectors(self, din_pad):
-        """[x || delta] gate weights split and padded: g[:Din_pad] multiplies x, g[Din_pad:] delta."""
-        din = self.lin_s.weight.shape[1]
+    def head(self):
+        """weights of this conv as one 'head' of the packed transform (ops.pack_transform_heads)."""
+        return {"W_s": self.lin_s.weight.detach(), "W_t": self.lin_t.weight.detach(),
+                "b_s": self.lin_s.bias.detach() if self.lin_s.bias is not None else None,
+                "b_t": self.lin_t.bias.detach() if self.lin_t.bias is not None else None,
+                "g_s2t": self.a_g_s2t.weight.detach(), "g_t2s": self.a_g_t2s.weight.detach()}
 
-        def split(w):
-            w = w.detach().reshape(-1)
-            g = torch.zeros(2 * din_pad, dtype=torch.float32, device=w.device)
-            g[:din] = w[:din]
-            g[din_pad:din_pad + din] = w[din:]
-            return g
-        return split(self.a_g_s2t.weight), split(self.a_g_t2s.weight)
+    def _versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def transform(self, x, mask_u8, delta=None, sums=None, out=None):
-        """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]."""
+    def packed(self, din_pad, partner=None):
+        """cached packed weights (re-packed when any parameter changed in place or moved)."""
+        key = (din_pad, self._versions(), partner._versions() if partner is not None else None)
+        if getattr(self, "_pack_key", None) != key:
+            heads = [self.head()] + ([partner.head()] if partner is not None else [])
+            self._pack = ops.pack_transform_heads(heads, din_pad)
+            self._pack_key = key
+        return self._pack
+
+    def transform(self, x, mask_u8, delta=None, sums=None, out=None, partner=None):
+        """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]; with `partner` (a second conv on the SAME
+        input) -> [(h_t2s, h_s2t), (h_t2s', h_s2t')] from one pass over x."""
         xp = _pad_cols4(x)
         din_pad = xp.shape[1]
         if delta is None:
             if sums is None:
                 sums = ops.domain_sums(xp, mask_u8)
             delta = ops.domain_delta(sums, din_pad)
-        g_s2t, g_t2s = self.gate_vectors(din_pad)
-        W_s, W_t = _pad_cols4(self.lin_s.weight.detach()), _pad_cols4(self.lin_t.weight.detach())
-        b_s = self.lin_s.bias.detach() if self.lin_s.bias is not None else None
-        b_t = self.lin_t.bias.detach() if self.lin_t.bias is not None else None
-        return ops.adaptedconv_transform(xp, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s, out=out)
+        res = ops.adaptedconv_transform(xp, mask_u8, delta, self.packed(din_pad, partner),
+                                        out=out if (out is None or partner is not None) else [out])
+        return res if partner is not None else res[0]
 
     def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None):
         """KTGNN.py:292-305 (+ optional fused BN-eval/ReLU epilogue)."""
@@ -257,19 +263,40 @@ class KTGNN_no_complement(nn.Module):
                 x = F.dropout(x, p=self.dropout, training=self.training)
         return x
 
+    def _transformer_eval(self, x):
+        """clf_transformer in eval mode with the BatchNorm folded into the first Linear (exact algebra:
+        BN(Wx+b) = (s*W)x + (s*b + t)); the ReLU rides in the GEMM epilogue when torch offers it."""
+        l0, bn, _, l3 = self.clf_transformer
+        key = tuple((p.data_ptr(), p._version) for p in self.clf_transformer.parameters()) + \
+            (bn.running_mean._version, bn.running_var._version)
+        if getattr(self, "_tf_key", None) != key:
+            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+            self._tf_w0t = (l0.weight.detach() * s[:, None]).t().contiguous()
+            self._tf_b0 = (l0.bias.detach() * s + bn.bias.detach() - bn.running_mean * s).contiguous()
+            self._tf_key = key
+        if hasattr(torch, "_addmm_activation"):
+            h = torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
+        else:
+            h = F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
+        return F.linear(h, l3.weight, l3.bias)
+
     def forward(self, data):
         x, central_mask = data.x, data.central_mask
         csr = self._prepare(data)
         x = self._hidden(x, csr, central_mask)
         x = x.contiguous()
-        # clf_base and clf_target(x) see the same input -> the domain means are shared
         mask_u8 = _as_u8(central_mask).contiguous()
-        xp = _pad_cols4(x)
-        delta = ops.domain_delta(ops.domain_sums(xp, mask_u8), xp.shape[1])
-        logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr, delta=delta)            # :432
-        xt = self.clf_transformer(x)
-        logits_hat = self.clf_target(xt, None, central_mask=central_mask, csr=csr)                        # :433
-        logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr, delta=delta)         # :434
+        if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled():
+            logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr)                      # :432
+            logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr)                  # :434
+        else:
+            # clf_base and clf_target(x) see the same input: ONE pass over x feeds both transforms
+            (bt2s, bs2t), (tt2s, ts2t) = self.clf_base.transform(x, mask_u8, partner=self.clf_target)
+            C = self.clf_base.out_channels
+            logits_base = self.clf_base.aggregate(bt2s, bs2t, csr, mask_u8)[:, :C]                       # :432
+            logits_target = self.clf_target.aggregate(tt2s, ts2t, csr, mask_u8)[:, :C]                   # :434
+        xt = self.clf_transformer(x) if self.training else self._transformer_eval(x)
+        logits_hat = self.clf_target(xt.contiguous(), None, central_mask=central_mask, csr=csr)           # :433
         return (F.log_softmax(logits_base, dim=1), F.log_softmax(logits_target, dim=1),
                 F.log_softmax(logits_hat, dim=1), None)                                                  # :435
 

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "adaptedconv_transform", "adaptedconv_aggregate",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "pad4"]
 
 
@@ -62,27 +62,54 @@ def domain_delta(sums, Din):
     return delta
 
 
-def adaptedconv_transform(x, mask_u8, delta, W_s, b_s, W_t, b_t, g_s2t, g_t2s, out=None):
-    """-> (h_t2s, h_s2t) as [N, ldh] tensors with ldh = pad4(D); columns >= D are zero.
-    `out=(h_t2s, h_s2t)` may pass larger preallocated tables (>= N rows, stride ldh): the first N rows
-    are written (multi-GPU: halo rows follow)."""
-    lib = L.lib()
-    N, Din = x.shape
-    D = W_s.shape[0]
+def pack_transform_heads(heads, din_pad):
+    """Pack 1-2 convs that share an input for `adaptedconv_transform`.  `heads` = list of dicts with
+    W_s, b_s, W_t, b_t ([D, Din] / [D] or None) and g_s2t, g_t2s ([2*Din], [x || delta] order).
+    -> (Wp [H*2*ldh, din_pad], bias_p [H*2*ldh], gates [H, 2, 2*din_pad], D, ldh)."""
+    D = heads[0]["W_s"].shape[0]
+    din = heads[0]["W_s"].shape[1]
     ldh = pad4(D)
+    dev = heads[0]["W_s"].device
+    H = len(heads)
+    Wp = torch.zeros(H * 2 * ldh, din_pad, dtype=torch.float32, device=dev)
+    bp = torch.zeros(H * 2 * ldh, dtype=torch.float32, device=dev)
+    gates = torch.zeros(H, 2, 2 * din_pad, dtype=torch.float32, device=dev)
+    for h, hd in enumerate(heads):
+        base = h * 2 * ldh
+        Wp[base: base + D, :din] = hd["W_t"]
+        Wp[base + ldh: base + ldh + D, :din] = hd["W_s"]
+        if hd.get("b_t") is not None:
+            bp[base: base + D] = hd["b_t"]
+        if hd.get("b_s") is not None:
+            bp[base + ldh: base + ldh + D] = hd["b_s"]
+        for t, key in enumerate(("g_s2t", "g_t2s")):
+            g = hd[key].reshape(-1)
+            gates[h, t, :din] = g[:din]
+            gates[h, t, din_pad: din_pad + din] = g[din:]
+    return Wp, bp, gates, D, ldh
+
+
+def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
+    """One pass over x -> per head (h_t2s, h_s2t) as [N, ldh] tensors (ldh = pad4(D); columns >= D are
+    zero).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
+    (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows)."""
+    lib = L.lib()
+    Wp, bp, gates, D, ldh = packed
+    H = gates.shape[0]
+    N, Din = x.shape
     dev = x.device
     if out is None:
-        h_t2s = torch.empty(N, ldh, dtype=torch.float32, device=dev)
-        h_s2t = torch.empty(N, ldh, dtype=torch.float32, device=dev)
-    else:
-        h_t2s, h_s2t = out
-        assert h_t2s.shape[0] >= N and h_s2t.shape[0] >= N and h_t2s.stride(0) == ldh and h_s2t.stride(0) == ldh
-    coef = torch.empty(max(N, 1) * 2, dtype=torch.float32, device=dev)
+        out = [(torch.empty(N, ldh, dtype=torch.float32, device=dev), torch.empty(N, ldh, dtype=torch.float32, device=dev))
+               for _ in range(H)]
+    for a, b in out:
+        assert a.shape[0] >= N and b.shape[0] >= N and a.stride(0) == ldh and b.stride(0) == ldh
+    small = torch.empty(H * (2 * ldh + 2) + 8, dtype=torch.float32, device=dev)
+    o1 = out[1] if H > 1 else (None, None)
     rc = lib.bgnn_adaptedconv_transform_f32(
-        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), L.ptr(W_s), L.ptr(b_s), L.ptr(W_t), L.ptr(b_t),
-        L.ptr(g_s2t), L.ptr(g_t2s), D, L.ptr(h_t2s), L.ptr(h_s2t), ldh, L.ptr(coef), L.stream())
+        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates),
+        L.ptr(out[0][1]), L.ptr(out[0][0]), L.ptr(o1[1]), L.ptr(o1[0]), ldh, L.ptr(small), L.stream())
     L.check(rc, "bgnn_adaptedconv_transform_f32")
-    return h_t2s, h_s2t
+    return out
 
 
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,

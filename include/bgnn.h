@@ -55,19 +55,25 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
  * bgnn_adaptedconv_transform_f32:                                               (:277-284)
  *   gate_s = tanh(x.g_s2t[:Din] + delta.g_s2t[Din:]),  gate_t likewise with g_t2s
  *   h_s2t = lin_t(x - gate_s*delta*[i in S]) ; h_t2s = lin_s(x + gate_t*delta*[i in T])
- *   W_* are [D, Din] row-major (torch Linear.weight), b_* [D] or NULL.  Outputs have leading
- *   dimension ldh >= D, ldh % 4 == 0; pad columns D..ldh-1 are written as 0.
- *   The GEMM runs on fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 fmaf chains.
- * coef_ws: N*2 floats of scratch (per-node gate coefficients).                               */
+ *   evaluated by linearity as  W x + b -/+ gate * (W delta)  in ONE pass over x (fp32 MFMA
+ *   v_mfma_f32_32x32x2_f32; the gate GEMVs ride in the staging loads, the rank-1 shift in the
+ *   epilogue).  Up to n_heads = 2 convs that share the input x (clf_base / clf_target,
+ *   KTGNN.py:432,:434) are evaluated together.
+ *   Wp     [n_heads*2*ldh, Din] packed weights: per head ldh rows of lin_t.weight (rows >= D zero)
+ *          followed by ldh rows of lin_s.weight (torch Linear.weight layout [out, in]);
+ *   bias_p [n_heads*2*ldh]      matching packed biases (zeros where absent / padded);
+ *   gates  [n_heads][2][2*Din]  a_g_s2t.weight then a_g_t2s.weight per head ([x || delta] order);
+ *   outputs per head have leading dimension ldh >= D, ldh % 4 == 0; pad columns come out as 0.
+ * small_ws: n_heads*(2*ldh+2) floats of scratch (W.delta and the gates' delta halves).       */
 int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
                          double* sums_io /*[2*Din+2]*/, void* stream);
 int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* delta, void* stream);
 int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                    const uint8_t* mask, const float* delta,
-                                   const float* W_s, const float* b_s, const float* W_t, const float* b_t,
-                                   const float* g_s2t, const float* g_t2s, int32_t D,
-                                   float* h_t2s, float* h_s2t, int64_t ldh,
-                                   float* coef_ws /*[N*2]*/, void* stream);
+                                   int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                   const float* gates,
+                                   float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                   int64_t ldh, float* small_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
