@@ -178,11 +178,29 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   }
 }
 
+// Persistent grid = exactly the blocks that are co-resident (occupancy x CUs): a larger grid would
+// leave late-starting blocks walking their strided tiles alone, long after their neighbours' rows
+// left the L2.  The hardware query is immutable, so it is cached per instantiation.
+template <int LF, int EP, int U>
+int resident_blocks() {
+  static const int nb = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_kernel<LF, EP, U>, 256, 0) != hipSuccess || per_cu < 1)
+      return 2048;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu * prop.multiProcessorCount / 8 * 8;
+  }();
+  return nb;
+}
+
 template <int LF, int EP, int U>
 int launch(const AggParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / (LF * EP));
   int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
-  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;   // multiple of 8 (XCD split), <= 8/CU
+  const int64_t cap = resident_blocks<LF, EP, U>();
+  int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;   // multiple of 8 (XCD split)
   if (grid < 8) grid = 8;
   hipLaunchKernelGGL((agg_kernel<LF, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
   BGNN_LAUNCH_CHECK();
@@ -208,11 +226,54 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
               out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu};
   hipStream_t st = (hipStream_t)stream;
   const int nv = (D + 3) / 4;   // float4 slots per row
-  if (nv <= 1) return launch<1, 8, 2>(p, st);
-  if (nv <= 2) return launch<2, 4, 2>(p, st);
-  if (nv <= 4) return launch<4, 4, 2>(p, st);
-  if (nv <= 8) return launch<8, 2, 4>(p, st);
-  if (nv <= 16) return launch<16, 2, 4>(p, st);
+  // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
+  // one sub-group per row with deep unrolling beats edge-parallel sub-groups except for the narrowest rows.
+  if (nv <= 1) return launch<1, 4, 4>(p, st);
+  if (nv <= 2) return launch<2, 2, 4>(p, st);
+  if (nv <= 4) return launch<4, 1, 8>(p, st);
+  if (nv <= 8) return launch<8, 1, 4>(p, st);
+  if (nv <= 16) return launch<16, 1, 8>(p, st);
   if (nv <= 32) return launch<32, 1, 4>(p, st);
   return launch<64, 1, 4>(p, st);
 }
+
+#ifdef BGNN_TUNING
+// Tuning-only entry (compiled into tools/libbgnn_tune.so, never into libbgnn_hip.so): run one explicit
+// (LF, EP, U) instantiation so a sweep can pick the dispatch table above from measurements.
+extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64_t ldh, const float* a_t2s,
+                                   const float* a_s2t, const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                   int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,
+                                   int variant, void* stream) {
+  AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
+              out, ldo, nullptr, nullptr, nullptr, 0};
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    // D = 128 (LF = 32)
+    case 0: return launch<32, 1, 4>(p, st);
+    case 1: return launch<32, 1, 8>(p, st);
+    case 2: return launch<32, 2, 4>(p, st);
+    case 3: return launch<32, 2, 2>(p, st);
+    case 4: return launch<32, 1, 2>(p, st);
+    case 5: return launch<32, 2, 8>(p, st);
+    // D <= 4 (LF = 1)
+    case 10: return launch<1, 8, 2>(p, st);
+    case 11: return launch<1, 4, 4>(p, st);
+    case 12: return launch<1, 2, 4>(p, st);
+    case 13: return launch<1, 1, 4>(p, st);
+    case 14: return launch<1, 1, 8>(p, st);
+    case 15: return launch<1, 4, 2>(p, st);
+    case 16: return launch<1, 2, 8>(p, st);
+    case 17: return launch<1, 16, 2>(p, st);
+    // D = 64 (LF = 16) / D = 32 (LF = 8)
+    case 20: return launch<16, 2, 4>(p, st);
+    case 21: return launch<16, 1, 4>(p, st);
+    case 22: return launch<16, 4, 2>(p, st);
+    case 23: return launch<16, 1, 8>(p, st);
+    case 30: return launch<8, 2, 4>(p, st);
+    case 31: return launch<8, 4, 2>(p, st);
+    case 32: return launch<8, 1, 4>(p, st);
+    case 33: return launch<8, 8, 2>(p, st);
+    default: return BGNN_E_RANGE;
+  }
+}
+#endif

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void domain_sums_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) { as[e] += sh[((q * 2 + 0) * cw + cl) * 4 + e]; at[e] += sh[((q * 2 + 1) * cw + cl) * 4 + e]; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(&sums[c4 * 4 + e], as[e]); atomicAdd(&sums[Din + c4 * 4 + e], at[e]); }
+      for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(&sums[c4 * 4 + e], as[e]); unsafeAtomicAdd(&sums[Din + c4 * 4 + e], at[e]); }  // hardware fp64 atomic add
     }
     __syncthreads();
   }
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void domain_sums_kernel(const float* __restric
   cs = bgnn::group_sum<64>(cs);
   ct = bgnn::group_sum<64>(ct);
   if ((tid & 63) == 0) {
-    atomicAdd(&sums[2 * Din], (double)cs);
-    atomicAdd(&sums[2 * Din + 1], (double)ct);
+    unsafeAtomicAdd(&sums[2 * Din], (double)cs);
+    unsafeAtomicAdd(&sums[2 * Din + 1], (double)ct);
   }
 }
 
@@ -286,7 +286,7 @@ extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int6
   if (N == 0) return 0;
   const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = 256 / cw;
   int64_t grid = (N + 63) / 64;
-  if (grid > 2048) grid = 2048;
+  if (grid > 1024) grid = 1024;      // few, long-running blocks: 1024 x 2*Din fp64 atomics in total
   hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(256), sizeof(double) * rl * 2 * cw * 4,
                      (hipStream_t)stream, x, N, Din, ldx, mask, sums_io);
   BGNN_LAUNCH_CHECK();
