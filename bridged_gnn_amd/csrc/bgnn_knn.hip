@@ -79,10 +79,12 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&v)[EPL], int lane) {
 }
 
 // ---- per-wave shortlist state in LDS -----------------------------------------------------------
-template <int EPL>
+// CAP buffer entries per query of which the best KP are "live"; the CAP-KP others absorb new arrivals
+// between two compactions.
+template <int CAPV, int KPV>
 struct WaveTopK {
-  static constexpr int CAP = 64 * EPL;   // buffer entries per query
-  static constexpr int KP = CAP / 2;     // live shortlist size
+  static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
+  static_assert(KPV < CAPV && CAPV - KPV >= 2 && CAPV <= 128, "shortlist geometry");
   u64* keys;                             // [QPW][CAP]
   int* cnt;                              // [QPW]
   float* tau;                            // [QPW]  current admission threshold (score of the KP-th best)
@@ -94,14 +96,18 @@ struct WaveTopK {
   // sort query q's buffer, keep the best KP, refresh tau.  Called by the whole wave (uniform q).
   __device__ __forceinline__ void compact(int q, int lane) {
     u64 v[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = keys[q * CAP + lane + 64 * e];
     const int n = min(cnt[q], CAP);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) if (lane + 64 * e >= n) v[e] = KEY_EMPTY;
+    for (int e = 0; e < EPL; ++e) {
+      const int i = lane + 64 * e;
+      v[e] = i < n ? keys[q * CAP + i] : KEY_EMPTY;
+    }
     wave_sort_desc<EPL>(v, lane);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) keys[q * CAP + lane + 64 * e] = v[e];
+    for (int e = 0; e < EPL; ++e) {
+      const int i = lane + 64 * e;
+      if (i < CAP) keys[q * CAP + i] = v[e];
+    }
     // KP-th best sits at global index KP-1: lane (KP-1)%64, element (KP-1)/64
     constexpr int TL = (KP - 1) % 64, TE = (KP - 1) / 64;
     const uint32_t kb = __shfl((uint32_t)(v[TE] >> 32), TL);
@@ -114,10 +120,9 @@ struct WaveTopK {
 };
 
 // Offer the 16 scores a lane holds (one query q = lane&31, candidates cand(r)) to the shortlist.
-template <int EPL>
-__device__ __forceinline__ void offer_tile(WaveTopK<EPL>& tk, const f32x16& acc, int cbase, int64_t Nc, int lane,
-                                           float& tau) {
-  constexpr int CAP = WaveTopK<EPL>::CAP;
+template <class TK>
+__device__ __forceinline__ void offer_tile(TK& tk, const f32x16& acc, int cbase, int64_t Nc, int lane, float& tau) {
+  constexpr int CAP = TK::CAP;
   const int q = lane & 31, h = lane >> 5;
   bool any = false;
 #pragma unroll
@@ -145,17 +150,17 @@ __device__ __forceinline__ void offer_tile(WaveTopK<EPL>& tk, const f32x16& acc,
         tau = tk.tau[q];
         pass = pass && (acc[r] > tau);
       }
-      if (++guard > 4) break;   // cannot trigger: after a compaction CAP-KP >= 32 slots are free
+      if (++guard > 4) break;   // cannot trigger: after a compaction CAP-KP >= 2 slots are free, <= 2 lanes per query pend
     }
   }
 }
 
 // final: sort each query's buffer and emit the best KP (score, idx) pairs, descending
-template <int EPL>
-__device__ __forceinline__ void emit_shortlists(WaveTopK<EPL>& tk, int lane, int64_t q0, int64_t Nq,
+template <class TK>
+__device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, int64_t Nq,
                                                 float* __restrict__ sl_score, int32_t* __restrict__ sl_idx,
                                                 int split, int nsplit) {
-  constexpr int CAP = WaveTopK<EPL>::CAP, KP = WaveTopK<EPL>::KP;
+  constexpr int CAP = TK::CAP, KP = TK::KP, EPL = TK::EPL;
   for (int q = 0; q < QPW; ++q) {
     tk.compact(q, lane);
     const int64_t gq = q0 + q;
@@ -176,56 +181,45 @@ __device__ __forceinline__ void emit_shortlists(WaveTopK<EPL>& tk, int lane, int
 
 // ------------------------------------------------------------------------------------------------
 // pass 1, cosine: scores = Qn_cand_tile (A, 32 x d) . Qn_query_block^T (B, d x 32) on fp32 MFMA.
-// DK = d / 8.  LDS: CHUNK x (d+4) floats staging (register-prefetched) + per-wave shortlists.
-template <int DK, int EPL>
-__global__ __launch_bounds__(256, 1) void cosine_pass1_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
-                                                              int64_t Nq, int64_t Nc, int nsplit,
-                                                              float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
-  constexpr int D = DK * 8, LD = D + 4;
-  constexpr int CAP = WaveTopK<EPL>::CAP;
-  constexpr int CHUNK = EPL == 1 ? 64 : 32;     // candidates staged per barrier pair
+// DK = d / 8.  Work = (query block, candidate tile) pairs, query-major; every persistent block takes one
+// CONTIGUOUS range of `tpb` tiles (perfect balance, no tail), emitting one shortlist per query-block
+// segment it touches (slot = block - first block touching that query block).
+template <int DK, int CAPV, int KPV>
+__global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
+                                                           int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
+                                                           float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  typedef WaveTopK<CAPV, KPV> TK;
+  constexpr int D = DK * 8, LD = D + 4, CAP = TK::CAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* stage = reinterpret_cast<float*>(smem);                               // [CHUNK][LD]
-  u64* keys_all = reinterpret_cast<u64*>(smem + sizeof(float) * CHUNK * LD);   // [WAVES][QPW][CAP]
+  float* stage = reinterpret_cast<float*>(smem);                           // [CT][LD]
+  u64* keys_all = reinterpret_cast<u64*>(smem + sizeof(float) * CT * LD);  // [WAVES][QPW][CAP]
   int* cnt_all = reinterpret_cast<int*>(keys_all + WAVES * QPW * CAP);
   float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int split = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
-  // candidate range of this split (multiple of 64 so tiles never straddle splits)
-  const int64_t per = ((Nc + nsplit - 1) / nsplit + 63) / 64 * 64;
-  const int64_t c_begin = min((int64_t)split * per, Nc), c_end = min(c_begin + per, Nc);
+  const int64_t ntiles = (Nc + CT - 1) / CT;
+  const int64_t nqb = (Nq + QPB - 1) / QPB;
+  const int64_t T = nqb * ntiles;
+  int64_t t = (int64_t)blockIdx.x * tpb;
+  const int64_t t_end = min(T, t + tpb);
 
-  WaveTopK<EPL> tk;
+  TK tk;
   tk.keys = keys_all + wave * QPW * CAP;
   tk.cnt = cnt_all + wave * QPW;
   tk.tau = tau_all + wave * QPW;
-  tk.init(lane);
 
-  // B fragments (this wave's 32 queries), resident for the whole kernel:
-  // lane (j = lane&31, h = lane>>5) holds q[j][8kb + 4h + s], s = 0..3
-  float4 bq[DK];
-  {
-    const int64_t gq = q0 + (lane & 31);
-    const int h = lane >> 5;
-#pragma unroll
-    for (int kb = 0; kb < DK; ++kb)
-      bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // staging: CHUNK x D floats = CHUNK*D/4 float4 over 256 threads
+  // staging: CT x D floats over 256 threads
   constexpr int F4_PER_ROW = D / 4;
-  constexpr int NLD = CHUNK * F4_PER_ROW / 256;
-  static_assert(CHUNK * F4_PER_ROW % 256 == 0 && NLD >= 1, "staging split");
+  constexpr int NLD = CT * F4_PER_ROW / 256;
+  static_assert(CT * F4_PER_ROW % 256 == 0 && NLD >= 1, "staging split");
   float4 pre[NLD];
-  auto gload = [&](int64_t cb) {
+  auto gload = [&](int64_t ct) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + 256 * j;
       const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      const int64_t gc = cb + r;
-      pre[j] = gc < c_end ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t gc = ct * CT + r;
+      pre[j] = gc < Nc ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto sstore = [&]() {
@@ -236,35 +230,46 @@ __global__ __launch_bounds__(256, 1) void cosine_pass1_kernel(const float* __res
       *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) = pre[j];
     }
   };
-
-  float tau = -INFINITY;
   const int fr = lane & 31, fh = lane >> 5;
-  if (c_begin < c_end) gload(c_begin);
-  for (int64_t cb = c_begin; cb < c_end; cb += CHUNK) {
-    sstore();
-    __syncthreads();
-    if (cb + CHUNK < c_end) gload(cb + CHUNK);     // next chunk flies while this one is scored
+
+  while (t < t_end) {                               // block-uniform: one segment per query block touched
+    const int64_t qb = t / ntiles, ct0 = t % ntiles;
+    const int64_t ct1 = min(ntiles, ct0 + (t_end - t));
+    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
+    const int64_t q0 = qb * QPB + wave * QPW;
+    tk.init(lane);
+    // B fragments (this wave's 32 queries): lane (j = lane&31, h = lane>>5) holds q[j][8kb + 4h + s], s = 0..3
+    float4 bq[DK];
+    {
+      const int64_t gq = q0 + fr;
 #pragma unroll
-    for (int t = 0; t < CHUNK / CT; ++t) {
-      if (cb + t * CT < c_end) {      // block-uniform
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* arow = &stage[(t * CT + fr) * LD + fh * 4];
-#pragma unroll
-        for (int kb = 0; kb < DK; ++kb) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
-        }
-        offer_tile<EPL>(tk, acc, (int)(cb + t * CT), c_end, lane, tau);
-      }
+      for (int kb = 0; kb < DK; ++kb)
+        bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+    float tau = -INFINITY;
+    gload(ct0);
+    for (int64_t ct = ct0; ct < ct1; ++ct) {
+      sstore();
+      __syncthreads();
+      if (ct + 1 < ct1) gload(ct + 1);             // next tile flies while this one is scored
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* arow = &stage[fr * LD + fh * 4];
+#pragma unroll
+      for (int kb = 0; kb < DK; ++kb) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
+      }
+      __syncthreads();                             // the stage buffer may be overwritten from here on
+      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau);
+    }
+    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
+    t += ct1 - ct0;
   }
-  emit_shortlists<EPL>(tk, lane, q0, Nq, sl_score, sl_idx, split, nsplit);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,8 +280,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ w2, float b2, int64_t Nq, int64_t Nc,
                                                            float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  typedef WaveTopK<64 * EPL, 32 * EPL> TK;
   constexpr int H = MLP_H, LD = H + 4;
-  constexpr int CAP = WaveTopK<EPL>::CAP;
+  constexpr int CAP = TK::CAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stage = reinterpret_cast<float*>(smem);                                    // [CT][LD]
   float* coefs = stage + CT * LD;                                                   // scale|shift|w2 [3][H]
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
   float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
-  WaveTopK<EPL> tk;
+  TK tk;
   tk.keys = keys_all + wave * QPW * CAP;
   tk.cnt = cnt_all + wave * QPW;
   tk.tau = tau_all + wave * QPW;
@@ -328,9 +334,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
         acc[r] = fmaf(w.w, fmaxf(fmaf(sc.w, a.w + bb.w, sh.w), 0.f), acc[r]);
       }
     }
-    offer_tile<EPL>(tk, acc, (int)cb, Nc, lane, tau);
+    offer_tile(tk, acc, (int)cb, Nc, lane, tau);
   }
-  emit_shortlists<EPL>(tk, lane, q0, Nq, sl_score, sl_idx, 0, 1);
+  emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, 0, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,19 +509,36 @@ struct TopkWs {
   int fb_blocks;
 };
 constexpr int FB_BLOCKS = 64;
-constexpr int MAX_SPLIT = 8;
-
-static int pick_nsplit(int64_t Nq, int64_t Nc) {
-  // candidate splits: fill the 256 CUs when there are few query blocks
-  const int64_t qblocks = (Nq + QPB - 1) / QPB;
-  int nsplit = 1;
-  while (nsplit < MAX_SPLIT && qblocks * nsplit < 512 && Nc / (nsplit * 2) >= 4096) nsplit *= 2;
-  return nsplit;
-}
 static int pick_kp(int k) { return k <= 24 ? 32 : 64; }
+constexpr int MAX_SLOTS = 8;
+
+// geometry of pass 1 for a problem: persistent blocks, tiles per block, shortlist slots per query
+struct Pass1Plan {
+  int64_t nblocks, tpb;
+  int nslots;
+};
+static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks) {
+  const int64_t ntiles = (Nc + CT - 1) / CT, nqb = (Nq + QPB - 1) / QPB, T = ntiles * nqb;
+  Pass1Plan pl;
+  pl.nblocks = T < resident_blocks ? T : resident_blocks;
+  if (pl.nblocks < 1) pl.nblocks = 1;
+  pl.tpb = (T + pl.nblocks - 1) / pl.nblocks;
+  const int64_t tpb_min = (ntiles + MAX_SLOTS - 2) / (MAX_SLOTS - 1);   // keep <= MAX_SLOTS shortlists per query
+  if (pl.tpb < tpb_min) pl.tpb = tpb_min;
+  pl.nblocks = (T + pl.tpb - 1) / pl.tpb;
+  pl.nslots = (int)((ntiles + pl.tpb - 1) / pl.tpb) + 1;     // blocks that can touch one query block
+  return pl;
+}
+// upper bound used for workspace sizing when the occupancy query is not yet known: 2 blocks per CU, 256 CUs
+constexpr int64_t RESIDENT_MAX = 1024;
+static int worst_slots(int64_t Nq, int64_t Nc) {
+  int m = 2;
+  for (int64_t rb = 1; rb <= RESIDENT_MAX; rb *= 2) { const int s = plan_pass1(Nq, Nc, rb).nslots; if (s > m) m = s; }
+  return m;
+}
 
 static size_t topk_ws_bytes(int64_t Nq, int64_t Nc, int k) {
-  const size_t L = (size_t)pick_nsplit(Nq, Nc) * pick_kp(k);
+  const size_t L = (size_t)worst_slots(Nq, Nc) * pick_kp(k);
   size_t b = 0;
   b += bgnn_align_up(sizeof(float) * Nq * L, 256);
   b += bgnn_align_up(sizeof(int32_t) * Nq * L, 256);
@@ -525,7 +548,7 @@ static size_t topk_ws_bytes(int64_t Nq, int64_t Nc, int k) {
   return b + 256;
 }
 static TopkWs topk_carve(void* ws, int64_t Nq, int64_t Nc, int k) {
-  const size_t L = (size_t)pick_nsplit(Nq, Nc) * pick_kp(k);
+  const size_t L = (size_t)worst_slots(Nq, Nc) * pick_kp(k);
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { char* q = p; p += bgnn_align_up(bytes, 256); return q; };
   TopkWs w;
@@ -561,17 +584,30 @@ static int run_refine(const Canon& canon, int64_t Nq, int64_t Nc, int k, int KP,
   return 0;
 }
 
-template <int DK, int EPL>
-static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, int nsplit, const TopkWs& w,
+template <int DK, int CAPV, int KPV>
+static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, const TopkWs& w, int* nslots_out,
                                hipStream_t st) {
-  constexpr int D = DK * 8, LD = D + 4, CAP = 64 * EPL, CHUNK = EPL == 1 ? 64 : 32;
-  const size_t sh = sizeof(float) * CHUNK * LD + sizeof(u64) * WAVES * QPW * CAP + sizeof(int) * WAVES * QPW +
+  constexpr int D = DK * 8, LD = D + 4;
+  const size_t sh = sizeof(float) * CT * LD + sizeof(u64) * WAVES * QPW * CAPV + sizeof(int) * WAVES * QPW +
                     sizeof(float) * WAVES * QPW;
-  auto kern = cosine_pass1_kernel<DK, EPL>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  auto kern = cosine_pass1_kernel<DK, CAPV, KPV>;
+  // immutable per (instantiation, device): how many blocks are co-resident
+  static const int resident = [&] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return -1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, sh) != hipSuccess || per_cu < 1) return -1;
+    if (per_cu > 2) per_cu = 2;                    // two waves per SIMD already cover each other's VALU phases
+    const int r = per_cu * prop.multiProcessorCount;
+    return r > (int)RESIDENT_MAX ? (int)RESIDENT_MAX : r;
+  }();
+  if (resident < 1) return (int)hipErrorInvalidValue;
+  const Pass1Plan pl = plan_pass1(Nq, Nc, resident);
+  *nslots_out = pl.nslots;
+  hipError_t e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st);   // every slot starts empty (-1)
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((Nq + QPB - 1) / QPB), (unsigned)nsplit), dim3(256), sh, st, qq, qc, Nq, Nc,
-                     nsplit, w.sl_score, w.sl_idx);
+  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nblocks), dim3(256), sh, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
@@ -604,13 +640,12 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   TopkWs w = topk_carve(ws, Nq, Nc, k);
-  const int epl = k <= 24 ? 1 : 2;
-  const int KP = 32 * epl;
-  const int nsplit = pick_nsplit(Nq, Nc);
+  const int KP = pick_kp(k);
+  int nsplit = 1;
   int rc;
 #define COS(DKV)                                                                                        \
-  rc = epl == 1 ? launch_cosine_pass1<DKV, 1>(qn_query, qn_cand, Nq, Nc, nsplit, w, st)                 \
-                : launch_cosine_pass1<DKV, 2>(qn_query, qn_cand, Nq, Nc, nsplit, w, st)
+  rc = KP == 32 ? launch_cosine_pass1<DKV, 48, 32>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
+                : launch_cosine_pass1<DKV, 128, 64>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)
   if (d == 32) { COS(4); } else if (d == 64) { COS(8); } else if (d == 128) { COS(16); } else { COS(32); }
 #undef COS
   if (rc) return rc;

@@ -130,9 +130,13 @@ struct GemmParams {
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile layout");
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+  // one LDS arena: [As0 | As1 | Bs0 | Bs1] during the K loop, re-used as the C staging tile afterwards
+  constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD, C_LD = BN + 4;
+  static_assert(BM * C_LD <= 2 * A_SZ + 2 * B_SZ, "C staging tile must fit in the A/B buffers");
+  __shared__ __attribute__((aligned(16))) float arena[2 * A_SZ + 2 * B_SZ];
   __shared__ float coef[BM][MAXH][2];
+  float* const As0 = arena;
+  float* const Bs0 = arena + 2 * A_SZ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch) -> give them the SAME
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(&As[buf][(sr + 32 * j) * LDS_LD + sc]) = ra[j];
+    for (int j = 0; j < APASS; ++j) *reinterpret_cast<float4*>(&As0[buf * A_SZ + (sr + 32 * j) * LDS_LD + sc]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(&Bs[buf][(sr + 32 * j) * LDS_LD + sc]) = rb[j];
+    for (int j = 0; j < BPASS; ++j) *reinterpret_cast<float4*>(&Bs0[buf * B_SZ + (sr + 32 * j) * LDS_LD + sc]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -218,10 +222,10 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        af[a] = *reinterpret_cast<const float4*>(&As[cur][((wm * TM + a) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
+        af[a] = *reinterpret_cast<const float4*>(&As0[cur * A_SZ + ((wm * TM + a) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
 #pragma unroll
       for (int c = 0; c < TN; ++c)
-        bf[c] = *reinterpret_cast<const float4*>(&Bs[cur][((wn * TN + c) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
+        bf[c] = *reinterpret_cast<const float4*>(&Bs0[cur * B_SZ + ((wn * TN + c) * 32 + fr) * LDS_LD + kb * 8 + fh * 4]);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -251,27 +255,44 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
       }
     }
   }
+  // epilogue, stage 1: accumulators -> LDS tile (the K loop ended with a barrier, the A/B buffers are free).
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* const Cs = arena;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        Cs[lr * C_LD + (wn * TN + c) * 32 + fr] = acc[a][c][r];
+      }
   __syncthreads();
-
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int ld2 = 2 * (int)p.ldh;
-#pragma unroll
-  for (int c = 0; c < TN; ++c) {
-    const int col = col0 + (wn * TN + c) * 32 + fr;
-    if (col < p.NC) {
-      const int h = col / ld2, rem = col % ld2;
-      const int t = rem >= p.ldh ? 1 : 0;
-      const int cc = rem - t * (int)p.ldh;
-      const float bv = p.bias[col], wv = p.wd[col];
-      float* __restrict__ out = p.out[h][t];
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lr = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const int64_t row = row0 + lr;
-          if (row < p.N) out[row * p.ldh + cc] = fmaf(coef[lr][h][t], wv, acc[a][c][r] + bv);
-        }
+  // stage 2: whole rows leave as 16-byte stores (a dword-per-lane epilogue is store-issue bound),
+  // with bias + rank-1 shift applied on the way out
+  constexpr int F4R = BN / 4;                   // float4 per tile row
+  constexpr int RPP = 256 / F4R;                // rows per pass
+  const int c4 = tid % F4R, rr = tid / F4R;
+  const int col = col0 + c4 * 4;
+  if (col < p.NC) {                             // NC % 4 == 0: a float4 is entirely in or out
+    const int ld2 = 2 * (int)p.ldh;
+    const int h = col / ld2, rem = col % ld2;
+    const int t = rem >= p.ldh ? 1 : 0;
+    const int cc = rem - t * (int)p.ldh;
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+    const float4 wv = *reinterpret_cast<const float4*>(p.wd + col);
+    float* __restrict__ out = p.out[h][t];
+#pragma unroll 4
+    for (int lr = rr; lr < BM; lr += RPP) {
+      const int64_t row = row0 + lr;
+      if (row < p.N) {
+        const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * C_LD + c4 * 4]);
+        const float cf = coef[lr][h][t];
+        float4 o;
+        o.x = fmaf(cf, wv.x, v.x + bv.x); o.y = fmaf(cf, wv.y, v.y + bv.y);
+        o.z = fmaf(cf, wv.z, v.z + bv.z); o.w = fmaf(cf, wv.w, v.w + bv.w);
+        *reinterpret_cast<float4*>(out + row * p.ldh + cc) = o;
+      }
     }
   }
 }
