@@ -264,8 +264,14 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
       }
+#if !defined(KNN_EXP) || KNN_EXP != 2
       __syncthreads();                             // the stage buffer may be overwritten from here on
+#endif
+#if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
+      asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
+#else
       offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau);
+#endif
     }
     emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
     t += ct1 - ct0;
