@@ -79,79 +79,174 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&v)[EPL], int lane) {
 }
 
 // ---- per-wave shortlist state in LDS -----------------------------------------------------------
-// CAP buffer entries per query of which the best KP are "live"; the CAP-KP others absorb new arrivals
-// between two compactions.
+// Per query: CAP buffer entries of which the best KP are "live"; the CAP-KP others absorb arrivals
+// between two compactions.  Per wave: a small QUEUE of (key, query) pairs.  Scores that beat the lane's
+// threshold register are only queued while tiles stream (ballot-prefix offsets, no atomics, bounded
+// time -> the block barrier is never held up by one wave's bookkeeping); the queue is drained in
+// batches of 64 (one LDS atomic round for the whole batch) every few tiles.
+constexpr int QCAP = 128;                  // queue entries per wave
+constexpr int DRAIN_EVERY = 8;             // tiles between unconditional drains (all waves drain together)
+
 template <int CAPV, int KPV>
 struct WaveTopK {
   static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
   static_assert(KPV < CAPV && CAPV - KPV >= 2 && CAPV <= 128, "shortlist geometry");
+  static constexpr size_t BYTES = sizeof(u64) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW +
+                                  sizeof(u64) * QCAP + sizeof(int) * QCAP;
   u64* keys;                             // [QPW][CAP]
   int* cnt;                              // [QPW]
   float* tau;                            // [QPW]  current admission threshold (score of the KP-th best)
+  u64* qkey;                             // [QCAP] queued keys
+  int* qqry;                             // [QCAP] their query (0..31)
+  int qcount;                            // wave-uniform
 
+  __device__ __forceinline__ void carve(unsigned char* base) {
+    keys = reinterpret_cast<u64*>(base);
+    qkey = keys + QPW * CAP;
+    cnt = reinterpret_cast<int*>(qkey + QCAP);
+    tau = reinterpret_cast<float*>(cnt + QPW);
+    qqry = reinterpret_cast<int*>(tau + QPW);
+  }
   __device__ __forceinline__ void init(int lane) {
     for (int t = lane; t < QPW * CAP; t += 64) keys[t] = KEY_EMPTY;
     if (lane < QPW) { cnt[lane] = 0; tau[lane] = -INFINITY; }
+    qcount = 0;
   }
-  // sort query q's buffer, keep the best KP, refresh tau.  Called by the whole wave (uniform q).
+  // keep the best KP entries of query q (sorted descending), refresh tau.  Whole wave, uniform q.
   __device__ __forceinline__ void compact(int q, int lane) {
-    u64 v[EPL];
     const int n = min(cnt[q], CAP);
+    if constexpr (EPL == 1) {
+      // rank by counting: CAP broadcasts (v_readlane) instead of a 21-stage shuffle network
+      const u64 key = lane < n ? keys[q * CAP + lane] : KEY_EMPTY;
+      const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+      int rank = 0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int i = lane + 64 * e;
-      v[e] = i < n ? keys[q * CAP + i] : KEY_EMPTY;
-    }
-    wave_sort_desc<EPL>(v, lane);
+      for (int j = 0; j < CAP; ++j) {
+        const u64 kj = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+        rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;     // equal keys only among EMPTY slots
+      }
+      if (lane < CAP) keys[q * CAP + rank] = key;
+      if (rank == KP - 1 && lane < CAP) tau[q] = (n >= KP) ? unord_f32(khi) : -INFINITY;
+      if (lane == 0) cnt[q] = n < KP ? n : KP;
+    } else {
+      u64 v[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int i = lane + 64 * e;
-      if (i < CAP) keys[q * CAP + i] = v[e];
-    }
-    // KP-th best sits at global index KP-1: lane (KP-1)%64, element (KP-1)/64
-    constexpr int TL = (KP - 1) % 64, TE = (KP - 1) / 64;
-    const uint32_t kb = __shfl((uint32_t)(v[TE] >> 32), TL);
-    if (lane == 0) {
-      const int nn = n < KP ? n : KP;
-      cnt[q] = nn;
-      tau[q] = (n >= KP) ? unord_f32(kb) : -INFINITY;
+      for (int e = 0; e < EPL; ++e) {
+        const int i = lane + 64 * e;
+        v[e] = i < n ? keys[q * CAP + i] : KEY_EMPTY;
+      }
+      wave_sort_desc<EPL>(v, lane);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int i = lane + 64 * e;
+        if (i < CAP) keys[q * CAP + i] = v[e];
+      }
+      constexpr int TL = (KP - 1) % 64, TE = (KP - 1) / 64;
+      const uint32_t kb = __shfl((uint32_t)(v[TE] >> 32), TL);
+      if (lane == 0) {
+        cnt[q] = n < KP ? n : KP;
+        tau[q] = (n >= KP) ? unord_f32(kb) : -INFINITY;
+      }
     }
   }
 };
 
-// Offer the 16 scores a lane holds (one query q = lane&31, candidates cand(r)) to the shortlist.
 template <class TK>
-__device__ __forceinline__ void offer_tile(TK& tk, const f32x16& acc, int cbase, int64_t Nc, int lane, float& tau) {
+__device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
+  while (qmask) {
+    const int qq = __ffs(qmask) - 1;
+    qmask &= qmask - 1;
+    tk.compact(qq, lane);
+  }
+}
+
+// Move the queued pairs into the per-query buffers, 64 at a time; full buffers are compacted and the
+// affected pairs re-checked against the raised threshold.
+template <class TK>
+__device__ __noinline__ void drain_queue(TK tk, int n, int lane) {
   constexpr int CAP = TK::CAP;
-  const int q = lane & 31, h = lane >> 5;
-  bool any = false;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) any |= acc[r] > tau;
-  if (!__any(any)) return;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int cand = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-    bool pass = (acc[r] > tau) && (cand < Nc);
-    int guard = 0;
-    while (__any(pass)) {
-      if (pass) {
-        const int slot = atomicAdd(&tk.cnt[q], 1);
-        if (slot < CAP) { tk.keys[q * CAP + slot] = make_key(acc[r], cand); pass = false; }
+  for (int base = 0; base < n; base += 64) {
+    const int e = base + lane;
+    const bool have = e < n;
+    const u64 key = have ? tk.qkey[e] : KEY_EMPTY;
+    const int qi = have ? tk.qqry[e] : 0;
+    bool pend = have && key_score(key) > tk.tau[qi];
+    for (int guard = 0; guard < 64; ++guard) {
+      if (pend) {
+        const int slot = atomicAdd(&tk.cnt[qi], 1);
+        if (slot < CAP) { tk.keys[qi * CAP + slot] = key; pend = false; }
       }
-      const unsigned long long over = __ballot(pass);
-      if (over) {
-        // rows that overflowed: compact each (wave-uniform loop over the distinct queries)
-        unsigned int qmask = (unsigned int)(over | (over >> 32));
-        while (qmask) {
-          const int qq = __ffs(qmask) - 1;
-          qmask &= qmask - 1;
-          tk.compact(qq, lane);
-        }
-        tau = tk.tau[q];
-        pass = pass && (acc[r] > tau);
+      unsigned long long over = __ballot(pend);
+      if (!over) break;
+      unsigned int qmask = 0;                       // distinct queries that overflowed
+      while (over) {
+        const int lead = __ffsll((long long)over) - 1;
+        const int qsel = __builtin_amdgcn_readlane(qi, lead);
+        qmask |= 1u << qsel;
+        over &= ~__ballot(pend && qi == qsel);
       }
-      if (++guard > 4) break;   // cannot trigger: after a compaction CAP-KP >= 2 slots are free, <= 2 lanes per query pend
+      compact_rows(tk, qmask, lane);
+      pend = pend && key_score(key) > tk.tau[qi];
     }
+  }
+}
+
+__device__ __forceinline__ float select16(const f32x16& acc, int r) {
+  float v = acc[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) v = (r == i) ? acc[i] : v;
+  return v;
+}
+
+// Offer the 16 scores a lane holds (one query q = lane&31, candidates cbase + cand(r)).
+template <class TK>
+__device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int lane, float& tau,
+                                           bool force_drain) {
+  const int q = lane & 31, h = lane >> 5;
+  if (cbase + CT > Nc) {                            // last (partial) tile only: mask candidates >= Nc
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (cbase + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) acc[r] = -INFINITY;
+  }
+  float mx = acc[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+#if defined(KNN_EXP) && KNN_EXP == 4
+  if (__any(mx > tau)) asm volatile("" ::"v"(acc[3]));
+  return;                                         // timing experiment: fast-path test only
+#endif
+  if (__any(mx > tau)) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (acc[r] > tau) ? (1u << r) : 0u;
+    while (true) {                                  // one queued score per lane and round, lowest register first
+      const bool pend = m != 0;
+      const unsigned long long b = __ballot(pend);
+      if (!b) break;
+      if (pend) {
+        const int r = __ffs(m) - 1;
+        const int off = tk.qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        tk.qkey[off] = make_key(select16(acc, r), cbase + (r & 3) + 8 * (r >> 2) + 4 * h);
+        tk.qqry[off] = q;
+        m &= m - 1;
+      }
+      tk.qcount += __popcll(b);
+      if (tk.qcount > QCAP - 64) {                  // wave-uniform: the next round might not fit
+        drain_queue(tk, tk.qcount, lane);
+        tk.qcount = 0;
+        tau = tk.tau[q];
+        uint32_t keep = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep |= (acc[r] > tau) ? (1u << r) : 0u;
+        m &= keep;
+      }
+    }
+  }
+  if (force_drain && tk.qcount > 0) {
+    drain_queue(tk, tk.qcount, lane);
+    tk.qcount = 0;
+    tau = tk.tau[q];
   }
 }
 
@@ -161,8 +256,9 @@ __device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, in
                                                 float* __restrict__ sl_score, int32_t* __restrict__ sl_idx,
                                                 int split, int nsplit) {
   constexpr int CAP = TK::CAP, KP = TK::KP, EPL = TK::EPL;
+  if (tk.qcount > 0) { drain_queue(tk, tk.qcount, lane); tk.qcount = 0; }
+  compact_rows(tk, 0xFFFFFFFFu, lane);
   for (int q = 0; q < QPW; ++q) {
-    tk.compact(q, lane);
     const int64_t gq = q0 + q;
     if (gq < Nq) {
 #pragma unroll
@@ -189,12 +285,9 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
                                                            int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
                                                            float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
   typedef WaveTopK<CAPV, KPV> TK;
-  constexpr int D = DK * 8, LD = D + 4, CAP = TK::CAP;
+  constexpr int D = DK * 8, LD = D + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stage = reinterpret_cast<float*>(smem);                           // [CT][LD]
-  u64* keys_all = reinterpret_cast<u64*>(smem + sizeof(float) * CT * LD);  // [WAVES][QPW][CAP]
-  int* cnt_all = reinterpret_cast<int*>(keys_all + WAVES * QPW * CAP);
-  float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t ntiles = (Nc + CT - 1) / CT;
@@ -204,9 +297,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
   const int64_t t_end = min(T, t + tpb);
 
   TK tk;
-  tk.keys = keys_all + wave * QPW * CAP;
-  tk.cnt = cnt_all + wave * QPW;
-  tk.tau = tau_all + wave * QPW;
+  tk.carve(smem + sizeof(float) * CT * LD + (size_t)wave * TK::BYTES);
 
   // staging: CT x D floats over 256 threads
   constexpr int F4_PER_ROW = D / 4;
@@ -270,7 +361,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
 #if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
       asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
 #else
-      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau);
+      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
 #endif
     }
     emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
@@ -288,19 +379,13 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
                                                            float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
   typedef WaveTopK<64 * EPL, 32 * EPL> TK;
   constexpr int H = MLP_H, LD = H + 4;
-  constexpr int CAP = TK::CAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stage = reinterpret_cast<float*>(smem);                                    // [CT][LD]
   float* coefs = stage + CT * LD;                                                   // scale|shift|w2 [3][H]
-  u64* keys_all = reinterpret_cast<u64*>(coefs + 3 * H);
-  int* cnt_all = reinterpret_cast<int*>(keys_all + WAVES * QPW * CAP);
-  float* tau_all = reinterpret_cast<float*>(cnt_all + WAVES * QPW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
   TK tk;
-  tk.keys = keys_all + wave * QPW * CAP;
-  tk.cnt = cnt_all + wave * QPW;
-  tk.tau = tau_all + wave * QPW;
+  tk.carve(reinterpret_cast<unsigned char*>(coefs + 3 * H) + (size_t)wave * TK::BYTES);
   tk.init(lane);
   for (int t = tid; t < H; t += 256) { coefs[t] = scale[t]; coefs[H + t] = shift[t]; coefs[2 * H + t] = w2[t]; }
   float4 bqv[H / 4];                 // this lane's query row B[q][:], statically indexed (registers)
@@ -340,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
         acc[r] = fmaf(w.w, fmaxf(fmaf(sc.w, a.w + bb.w, sh.w), 0.f), acc[r]);
       }
     }
-    offer_tile(tk, acc, (int)cb, Nc, lane, tau);
+    offer_tile(tk, acc, (int)cb, Nc, lane, tau, true);
   }
   emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, 0, 1);
 }
@@ -594,8 +679,7 @@ template <int DK, int CAPV, int KPV>
 static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, const TopkWs& w, int* nslots_out,
                                hipStream_t st) {
   constexpr int D = DK * 8, LD = D + 4;
-  const size_t sh = sizeof(float) * CT * LD + sizeof(u64) * WAVES * QPW * CAPV + sizeof(int) * WAVES * QPW +
-                    sizeof(float) * WAVES * QPW;
+  const size_t sh = sizeof(float) * CT * LD + WAVES * WaveTopK<CAPV, KPV>::BYTES;
   auto kern = cosine_pass1_kernel<DK, CAPV, KPV>;
   // immutable per (instantiation, device): how many blocks are co-resident
   static const int resident = [&] {
@@ -678,9 +762,8 @@ extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query,
   const int epl = k <= 24 ? 1 : 2;
   const int KP = 32 * epl;
   {
-    const int CAP = 64 * epl;
-    const size_t sh = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H) + sizeof(u64) * WAVES * QPW * CAP +
-                      sizeof(int) * WAVES * QPW + sizeof(float) * WAVES * QPW;
+    const size_t sh = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H) +
+                      WAVES * (epl == 1 ? WaveTopK<64, 32>::BYTES : WaveTopK<128, 64>::BYTES);
     const unsigned grid = (unsigned)((Nq + QPB - 1) / QPB);
     hipError_t e;
     if (epl == 1) {
