@@ -13,6 +13,8 @@
 //      the shortlist; unproven rows are queued;
 //   3. queued rows are re-done exhaustively in canonical arithmetic.
 // Index results are therefore bit-identical to oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk.
+#include <cstdio>
+
 #include "bgnn_common.h"
 
 namespace {
@@ -84,21 +86,40 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&v)[EPL], int lane) {
 // threshold register are only queued while tiles stream (ballot-prefix offsets, no atomics, bounded
 // time -> the block barrier is never held up by one wave's bookkeeping); the queue is drained in
 // batches of 64 (one LDS atomic round for the whole batch) every few tiles.
+#if defined(KNN_EXP) && (KNN_EXP == 8 || KNN_EXP == 9 || KNN_EXP == 10)
+__device__ unsigned long long g_knn_cnt[8];
+__device__ unsigned long long g_knn_blk[1024 * 3];
+#define KCOUNT(i, v) do { if (KNN_EXP == 8 && lane == 0) atomicAdd(&g_knn_cnt[i], (unsigned long long)(v)); } while (0)
+#else
+#define KCOUNT(i, v) do { } while (0)
+#endif
+#if defined(KNN_EXP) && KNN_EXP == 9
+#define KSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define KACC(i, a, b) do { if (lane == 0) tk.dbg[i] += (b) - (a); } while (0)
+#else
+#define KSTAMP(var)
+#define KACC(i, a, b) do { } while (0)
+#endif
 constexpr int QCAP = 128;                  // queue entries per wave
-constexpr int DRAIN_EVERY = 8;             // tiles between unconditional drains (all waves drain together)
+#ifdef DRAIN_EVERY_OVERRIDE
+constexpr int DRAIN_EVERY = DRAIN_EVERY_OVERRIDE;
+#else
+constexpr int DRAIN_EVERY = 8;
+#endif             // tiles between unconditional drains (all waves drain together)
 
 template <int CAPV, int KPV>
 struct WaveTopK {
   static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
   static_assert(KPV < CAPV && CAPV - KPV >= 2 && CAPV <= 128, "shortlist geometry");
   static constexpr size_t BYTES = sizeof(u64) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW +
-                                  sizeof(u64) * QCAP + sizeof(int) * QCAP;
+                                  sizeof(u64) * QCAP + sizeof(int) * QCAP + 64;
   u64* keys;                             // [QPW][CAP]
   int* cnt;                              // [QPW]
   float* tau;                            // [QPW]  current admission threshold (score of the KP-th best)
   u64* qkey;                             // [QCAP] queued keys
   int* qqry;                             // [QCAP] their query (0..31)
   int qcount;                            // wave-uniform
+  unsigned long long* dbg;               // [8] cycle counters (diagnostic builds only)
 
   __device__ __forceinline__ void carve(unsigned char* base) {
     keys = reinterpret_cast<u64*>(base);
@@ -106,7 +127,9 @@ struct WaveTopK {
     cnt = reinterpret_cast<int*>(qkey + QCAP);
     tau = reinterpret_cast<float*>(cnt + QPW);
     qqry = reinterpret_cast<int*>(tau + QPW);
+    dbg = reinterpret_cast<unsigned long long*>(qqry + QCAP);
   }
+  __device__ __forceinline__ void kq_store(int q, int slot, u64 k) { keys[q * CAP + slot] = k; }
   __device__ __forceinline__ void init(int lane) {
     for (int t = lane; t < QPW * CAP; t += 64) keys[t] = KEY_EMPTY;
     if (lane < QPW) { cnt[lane] = 0; tau[lane] = -INFINITY; }
@@ -116,18 +139,35 @@ struct WaveTopK {
   __device__ __forceinline__ void compact(int q, int lane) {
     const int n = min(cnt[q], CAP);
     if constexpr (EPL == 1) {
-      // rank by counting: CAP broadcasts (v_readlane) instead of a 21-stage shuffle network
-      const u64 key = lane < n ? keys[q * CAP + lane] : KEY_EMPTY;
-      const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+      // rank by counting: every lane streams the query's CAP keys from LDS (same address in all lanes ->
+      // broadcast reads) and counts the larger ones; no shuffle network, ~3 VALU ops per key.
+      // Valid keys are unique (distinct candidate index) and all exceed KEY_EMPTY, so ranks of valid keys
+      // are a permutation of [0, n); slots >= n are never read.
+      const u64* kq = keys + q * CAP;
+      const u64 key = lane < n ? kq[lane] : KEY_EMPTY;
       int rank = 0;
+      // batches of 16 keys (8 x ds_read_b128, independent, issued back to back), then 16 compares
+      static_assert(CAP % 8 == 0, "CAP multiple of 8");
 #pragma unroll
-      for (int j = 0; j < CAP; ++j) {
-        const u64 kj = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) |
-                       (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
-        rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;     // equal keys only among EMPTY slots
+      for (int j0 = 0; j0 < CAP; j0 += 16) {
+        constexpr int NB = 16;
+        u64 kk[NB];
+#pragma unroll
+        for (int t = 0; t < NB; t += 2) {
+          if (j0 + t < CAP) {
+            const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(kq + j0 + t);
+            kk[t] = two.x; kk[t + 1] = two.y;
+          } else { kk[t] = KEY_EMPTY; kk[t + 1] = KEY_EMPTY; }
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const u64 kj = (j0 + t < n) ? kk[t] : KEY_EMPTY;
+          rank += (kj > key) ? 1 : 0;
+        }
       }
-      if (lane < CAP) keys[q * CAP + rank] = key;
-      if (rank == KP - 1 && lane < CAP) tau[q] = (n >= KP) ? unord_f32(khi) : -INFINITY;
+      __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): all reads of the old order done before the scatter
+      if (lane < n) kq_store(q, rank, key);
+      if (lane < n && rank == KP - 1) tau[q] = unord_f32((uint32_t)(key >> 32));
       if (lane == 0) cnt[q] = n < KP ? n : KP;
     } else {
       u64 v[EPL];
@@ -154,11 +194,15 @@ struct WaveTopK {
 
 template <class TK>
 __device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
+  KSTAMP(c0);
   while (qmask) {
     const int qq = __ffs(qmask) - 1;
     qmask &= qmask - 1;
+    KCOUNT(4, 1);
     tk.compact(qq, lane);
   }
+  KSTAMP(c1);
+  KACC(5, c0, c1);
 }
 
 // Move the queued pairs into the per-query buffers, 64 at a time; full buffers are compacted and the
@@ -166,6 +210,11 @@ __device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
 template <class TK>
 __device__ __noinline__ void drain_queue(TK tk, int n, int lane) {
   constexpr int CAP = TK::CAP;
+#if defined(KNN_EXP) && KNN_EXP == 6
+  return;                                           // timing experiment: queueing only
+#endif
+  KCOUNT(3, 1);
+  KSTAMP(d0);
   for (int base = 0; base < n; base += 64) {
     const int e = base + lane;
     const bool have = e < n;
@@ -186,10 +235,16 @@ __device__ __noinline__ void drain_queue(TK tk, int n, int lane) {
         qmask |= 1u << qsel;
         over &= ~__ballot(pend && qi == qsel);
       }
+#if defined(KNN_EXP) && KNN_EXP == 7
+      if (lane < 32 && ((qmask >> lane) & 1)) tk.cnt[lane] = TK::KP;   // timing experiment: no compaction work
+#else
       compact_rows(tk, qmask, lane);
+#endif
       pend = pend && key_score(key) > tk.tau[qi];
     }
   }
+  KSTAMP(d1);
+  KACC(4, d0, d1);
 }
 
 __device__ __forceinline__ float select16(const f32x16& acc, int r) {
@@ -298,6 +353,10 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
 
   TK tk;
   tk.carve(smem + sizeof(float) * CT * LD + (size_t)wave * TK::BYTES);
+#if defined(KNN_EXP) && KNN_EXP == 9
+  if (lane < 8) tk.dbg[lane] = 0;
+  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // staging: CT x D floats over 256 threads
   constexpr int F4_PER_ROW = D / 4;
@@ -322,6 +381,14 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
     }
   };
   const int fr = lane & 31, fh = lane >> 5;
+#if defined(KNN_EXP) && KNN_EXP == 10
+  const unsigned long long cen0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if defined(KNN_STAGGER)
+  // de-phase the co-resident block pair of a CU (second wave of blocks lands on CUs that already host one):
+  // without it both run their MFMA chains and their bookkeeping at the same time (speed only)
+  if (blockIdx.x >= gridDim.x / 2) { for (int i = 0; i < KNN_STAGGER; ++i) __builtin_amdgcn_s_sleep(32); }
+#endif
 
   while (t < t_end) {                               // block-uniform: one segment per query block touched
     const int64_t qb = t / ntiles, ct0 = t % ntiles;
@@ -340,13 +407,18 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
     float tau = -INFINITY;
     gload(ct0);
     for (int64_t ct = ct0; ct < ct1; ++ct) {
+      KSTAMP(s0);
       sstore();
       __syncthreads();
+      KSTAMP(s1);
       if (ct + 1 < ct1) gload(ct + 1);             // next tile flies while this one is scored
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* arow = &stage[fr * LD + fh * 4];
+#if defined(KNN_PRIO)
+      __builtin_amdgcn_s_setprio(KNN_PRIO);
+#endif
 #pragma unroll
       for (int kb = 0; kb < DK; ++kb) {
         const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
@@ -355,18 +427,35 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
       }
+#if defined(KNN_PRIO)
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      KSTAMP(s2);
 #if !defined(KNN_EXP) || KNN_EXP != 2
       __syncthreads();                             // the stage buffer may be overwritten from here on
 #endif
+      KSTAMP(s3);
 #if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
       asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
 #else
       offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
 #endif
+      KSTAMP(s4);
+      KACC(1, s0, s1); KACC(0, s1, s2); KACC(2, s2, s3); KACC(3, s3, s4);
     }
     emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
     t += ct1 - ct0;
   }
+#if defined(KNN_EXP) && KNN_EXP == 10
+  if (tid == 0 && blockIdx.x < 1024) { g_knn_blk[blockIdx.x * 3] = cen0; g_knn_blk[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_knn_blk[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid; }
+#endif
+#if defined(KNN_EXP) && KNN_EXP == 9
+  if (lane == 0) { tk.dbg[6] = __builtin_amdgcn_s_memtime() - kt0; tk.dbg[7] = __builtin_amdgcn_s_memrealtime() - kr0; }
+  if (tid == 0 && blockIdx.x < 1024) { g_knn_blk[blockIdx.x * 3] = kr0; g_knn_blk[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_knn_blk[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid; }
+  if (lane < 8) atomicAdd(&g_knn_cnt[lane], tk.dbg[lane]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,7 +689,11 @@ struct TopkWs {
   int fb_blocks;
 };
 constexpr int FB_BLOCKS = 64;
-static int pick_kp(int k) { return k <= 24 ? 32 : 64; }
+#ifndef KNN_KP_SMALL
+#define KNN_KP_SMALL 24      // live shortlist size for k <= KNN_KP_SMALL - 4
+#define KNN_CAP_SMALL 48
+#endif
+static int pick_kp(int k) { return k <= KNN_KP_SMALL - 4 ? KNN_KP_SMALL : (k <= 24 ? 32 : 64); }
 constexpr int MAX_SLOTS = 8;
 
 // geometry of pass 1 for a problem: persistent blocks, tiles per block, shortlist slots per query
@@ -681,19 +774,30 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
   constexpr int D = DK * 8, LD = D + 4;
   const size_t sh = sizeof(float) * CT * LD + WAVES * WaveTopK<CAPV, KPV>::BYTES;
   auto kern = cosine_pass1_kernel<DK, CAPV, KPV>;
-  // immutable per (instantiation, device): how many blocks are co-resident
+  // immutable per (instantiation, device): how many blocks are co-resident.  The occupancy API prices LDS
+  // against 64 KB per CU on ROCm 7.2 and answers 1 here; gfx950 has 160 KB per CU, and this kernel's
+  // <= 256 VGPRs allow two waves per SIMD, so the residency is computed from those two budgets.
   static const int resident = [&] {
-    int per_cu = 0, dev = 0;
+    int dev = 0;
     hipDeviceProp_t prop;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return -1;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, sh) != hipSuccess || per_cu < 1) return -1;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) != hipSuccess) return -1;
+    int per_cu = (int)((160 * 1024) / sh);          // the kernel has no static LDS
+    const int by_regs = fa.numRegs > 0 ? 512 / ((fa.numRegs + 7) / 8 * 8) : 1;     // waves per SIMD = blocks per CU (4 waves)
+    if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu > 2) per_cu = 2;                    // two waves per SIMD already cover each other's VALU phases
+    if (per_cu < 1) per_cu = 1;
     const int r = per_cu * prop.multiProcessorCount;
     return r > (int)RESIDENT_MAX ? (int)RESIDENT_MAX : r;
   }();
   if (resident < 1) return (int)hipErrorInvalidValue;
   const Pass1Plan pl = plan_pass1(Nq, Nc, resident);
+#if defined(KNN_EXP)
+  { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+    fprintf(stderr, "[knn] resident=%d nblocks=%lld tpb=%lld nslots=%d sh=%zu numRegs=%d static=%zu\n", resident, (long long)pl.nblocks, (long long)pl.tpb, pl.nslots, sh, fa.numRegs, (size_t)fa.sharedSizeBytes); }
+#endif
   *nslots_out = pl.nslots;
   hipError_t e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st);   // every slot starts empty (-1)
   if (e != hipSuccess) return (int)e;
@@ -734,7 +838,8 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   int nsplit = 1;
   int rc;
 #define COS(DKV)                                                                                        \
-  rc = KP == 32 ? launch_cosine_pass1<DKV, 48, 32>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
+  rc = KP == KNN_KP_SMALL ? launch_cosine_pass1<DKV, KNN_CAP_SMALL, KNN_KP_SMALL>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st) \
+     : KP == 32 ? launch_cosine_pass1<DKV, 48, 32>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
                 : launch_cosine_pass1<DKV, 128, 64>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)
   if (d == 32) { COS(4); } else if (d == 64) { COS(8); } else if (d == 128) { COS(16); } else { COS(32); }
 #undef COS
@@ -782,3 +887,13 @@ extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query,
   MlpCanon canon{A_cand, B_query, bn_scale, bn_shift, w2, b2, H};
   return run_refine(canon, Nq, Nc, k, KP, 1, w, 1e-4, 1e-4, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
 }
+
+#if defined(KNN_EXP) && (KNN_EXP == 8 || KNN_EXP == 9 || KNN_EXP == 10)
+extern "C" int bgnn_debug_knn_blocks(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_knn_blk), sizeof(unsigned long long) * 1024 * 3);
+}
+extern "C" int bgnn_debug_knn_counters(unsigned long long* host_out) {
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_knn_cnt), sizeof(unsigned long long) * 8);
+  return (int)e;
+}
+#endif
