@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--knn-n", type=int, default=100_000)
+    ap.add_argument("--force-dist", action="store_true", help="run the partitioned (RCCL) code path even at world size 1")
     return ap.parse_args()
 
 
@@ -152,8 +153,11 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from bridged_gnn_amd import ops
@@ -165,7 +169,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(0)
     x_full = None
 
-    if world == 1:
+    if not use_dist:
         x = torch.randn(N, args.feat, device=dev, generator=gen)
         data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), central_mask=torch.from_numpy(mask_np).to(dev))
         t0 = time.perf_counter()
@@ -179,7 +183,7 @@ def main():
         from bridged_gnn_amd.dist import PartitionedKTGNN
         x_full = torch.randn(N, args.feat, device=dev, generator=gen)     # same seed on every rank
         t0 = time.perf_counter()
-        pk = PartitionedKTGNN(model, ei_np, mask_np, rank, world, dev)
+        pk = PartitionedKTGNN(model, ei_np, mask_np, rank, world, dev, always_communicate=args.force_dist)
         torch.cuda.synchronize()
         csr_ms = (time.perf_counter() - t0) * 1e3
         Eprime = pk.global_num_edges
@@ -207,7 +211,7 @@ def main():
     ops.adaptedconv_aggregate = timed_agg
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +226,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     timed_agg.on = False
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -230,8 +234,8 @@ def main():
     agg_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
 
     if rank == 0:
-        n_local = N if world == 1 else len(pk.owned_global)
-        e_local = Eprime if world == 1 else pk.local_num_edges
+        n_local = N if not use_dist else len(pk.owned_global)
+        e_local = Eprime if not use_dist else pk.local_num_edges
         bytes_launch = agg_bytes(e_local, n_local, args.hidden)
         achieved = bytes_launch / (agg_ms * 1e-3) / 1e9
         out = {
@@ -251,7 +255,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -128,8 +128,8 @@ class HaloExchange:
     CPU tensors).  `start` posts both all_to_all_single ops asynchronously, `wait` blocks the current
     stream on them; received rows land directly in table[n_local:]."""
 
-    def __init__(self, plan, device, group=None):
-        self.plan, self.group = plan, group
+    def __init__(self, plan, device, group=None, always=False):
+        self.plan, self.group, self.always = plan, group, always   # always: issue the collectives even at world 1
         self.send_rows = [torch.from_numpy(r).to(device) for r in plan.send_rows]
         self._work = []
 
@@ -142,7 +142,7 @@ class HaloExchange:
             send = tab.index_select(0, self.send_rows[t])            # [sum(send_splits), ld]
             recv = tab[p.n_local: p.n_local + p.n_halo[t]]
             self._keep.append(send)
-            if p.world == 1:
+            if p.world == 1 and not self.always:
                 continue
             w = dist.all_to_all_single(recv, send, output_split_sizes=p.recv_splits[t],
                                        input_split_sizes=p.send_splits[t], group=self.group, async_op=True)
@@ -157,9 +157,11 @@ class HaloExchange:
 class PartitionedKTGNN:
     """Eval forward of `KTGNN_no_complement` (models/KTGNN.py:401-435) on rank-local rows."""
 
-    def __init__(self, model, edge_index, central_mask, rank, world, device, owner=None, group=None):
+    def __init__(self, model, edge_index, central_mask, rank, world, device, owner=None, group=None,
+                 always_communicate=False):
         from . import ops
         self.model, self.rank, self.world, self.device, self.group = model, rank, world, device, group
+        self.always = always_communicate               # run the collectives even at world_size 1 (smoke-tests RCCL usage)
         plan = PartitionPlan(edge_index, central_mask, rank, world, owner=owner)
         self.plan = plan
         self.owned_global = torch.from_numpy(plan.owned_global).to(device)
@@ -168,7 +170,7 @@ class PartitionedKTGNN:
                               plan.local_num_edges, plan.n_local)
         self.mask_local = torch.from_numpy(plan.mask_local).to(device)
         self.mask_u8 = self.mask_local.to(torch.uint8).contiguous()
-        self.halo = HaloExchange(plan, device, group)
+        self.halo = HaloExchange(plan, device, group, always=always_communicate)
 
     def _conv(self, conv, x, epilogue=None, sums=None):
         from . import ops
@@ -177,7 +179,7 @@ class PartitionedKTGNN:
         xp = _pad_cols4(x)
         if sums is None:
             sums = ops.domain_sums(xp, self.mask_u8)
-            if self.world > 1:
+            if self.world > 1 or self.always:
                 dist.all_reduce(sums, group=self.group)              # 2*Din+2 doubles
         delta = ops.domain_delta(sums, xp.shape[1])
         ld = ops.pad4(conv.out_channels)
