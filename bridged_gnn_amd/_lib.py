@@ -25,6 +25,8 @@ SIGNATURES = {
                                                _P, _P, _P, _P, _I64, _P, _P]),
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
                                                _P, _I64, _P, _P, _P, _INT, _P]),
+    "bgnn_adaptedconv_aggregate_bwd_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
+                                                   _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "bgnn_l2_normalize_rows_f32": (_INT, [_P, _I64, _I32, _F32, _P, _P]),
     "bgnn_topk_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
     "bgnn_cosine_topk_f32": (_INT, [_P, _P, _I64, _I64, _I32, _I32, _INT, _P, _P, _P, _P, _SZ, _P]),

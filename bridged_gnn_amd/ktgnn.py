@@ -8,7 +8,9 @@ What is different by design (MI355X-first, results identical within 1e-5 relativ
   * gathers / attention GEMVs / PyG softmax / two propagate scatter-adds (:292-305) are one fused
     kernel; the shifted copies x_s2t / x_t2s (:279-280) are never materialised;
   * eval-mode BatchNorm1d + ReLU after a hidden conv (:425-430) ride in that kernel's epilogue.
-Backward is not implemented yet: forward under autograd raises.
+Training: under autograd the fused aggregation is a `torch.autograd.Function`
+whose backward is the HIP kernel `bgnn_adaptedconv_aggregate_bwd_f32`; the dense transform then runs
+as plain torch ops (rocBLAS GEMMs) in the reference's op order so torch differentiates it.
 """
 import math
 
@@ -61,6 +63,27 @@ def _pad_cols4(t):
     """zero-pad the last dim to a multiple of 4 (float4 loads in the kernels)."""
     pad = (-t.shape[-1]) % 4
     return t.contiguous() if pad == 0 else F.pad(t, (0, pad)).contiguous()
+
+
+class _AggregateFn(torch.autograd.Function):
+    """out = fused attention aggregation (KTGNN.py:292-305); backward = HIP kernel (atomics on the
+    scattered source-side sums)."""
+
+    @staticmethod
+    def forward(ctx, h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, slope):
+        h_t2s, h_s2t = h_t2s.contiguous(), h_s2t.contiguous()
+        a_t2s, a_s2t = a_t2s.contiguous(), a_s2t.contiguous()
+        out, alpha = ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, slope, want_alpha=True)
+        ctx.save_for_backward(h_t2s, h_s2t, a_t2s, a_s2t, out, alpha, mask_u8)
+        ctx.csr, ctx.D, ctx.slope = csr, D, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h_t2s, h_s2t, a_t2s, a_s2t, out, alpha, mask_u8 = ctx.saved_tensors
+        dh_t2s, dh_s2t, da_t2s, da_s2t = ops.adaptedconv_aggregate_bwd(
+            h_t2s, h_s2t, a_t2s, a_s2t, ctx.csr, mask_u8, ctx.D, out, alpha, grad_out.contiguous(), ctx.slope)
+        return dh_t2s, dh_s2t, da_t2s, da_s2t, None, None, None, None
 
 
 class AdaptedConv(nn.Module):
@@ -141,6 +164,24 @@ class AdaptedConv(nn.Module):
                                          self.negative_slope, n_dst=n_dst, want_alpha=want_alpha,
                                          ep_scale=sc, ep_shift=sh, ep_relu=relu)
 
+    def _forward_autograd(self, x, mask, mask_u8, csr):
+        """Differentiable path: dense part in torch (reference op order, KTGNN.py:275-284), fused
+        aggregation through `_AggregateFn`."""
+        D = self.out_channels
+        diff = x[mask].mean(0, keepdim=True) - x[~mask].mean(0, keepdim=True)                    # :275
+        diff = diff.expand(x.shape)
+        cat = torch.cat((x, diff), dim=-1)
+        shift_s2t = torch.tanh(self.a_g_s2t(cat)) * diff                                        # :277
+        shift_t2s = torch.tanh(self.a_g_t2s(cat)) * diff                                        # :278
+        h_s2t = self.lin_t(x - shift_s2t * mask.unsqueeze(-1))                                  # :279,:283
+        h_t2s = self.lin_s(x + shift_t2s * (~mask).unsqueeze(-1))                               # :280,:284
+        pad = ops.pad4(D) - D
+        if pad:
+            h_s2t, h_t2s = F.pad(h_s2t, (0, pad)), F.pad(h_t2s, (0, pad))
+        out = _AggregateFn.apply(h_t2s, h_s2t, self.a_f_t2s.weight.reshape(-1), self.a_f_s2t.weight.reshape(-1),
+                                 csr, mask_u8, D, self.negative_slope)
+        return out[:, :D]
+
     def _csr_for(self, edge_index, num_nodes):
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index.device.index, num_nodes)
         csr = self._csr_cache.get(key)
@@ -158,9 +199,6 @@ class AdaptedConv(nn.Module):
             x_src = x_r = x
         if not x_src.is_cuda:
             raise RuntimeError("AdaptedConv runs on MI355X only (CUDA/HIP tensors); there is no CPU path")
-        if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "AdaptedConv backward is not implemented yet (SURVEY.md 8(f) rank 1); call under torch.no_grad()")
         if central_mask is None:
             raise ValueError("central_mask is required")
         x_src = x_src.float()
@@ -168,6 +206,17 @@ class AdaptedConv(nn.Module):
         mask_u8 = _as_u8(central_mask).contiguous()
         if csr is None:
             csr = self._csr_for(edge_index, N)
+        if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in self.parameters())):
+            out = self._forward_autograd(x_src, central_mask.bool(), mask_u8, csr)
+            if self.root_weight and x_r is not None:
+                out = out + self.lin_r(x_r.float())
+            if self.normalize:
+                out = F.normalize(out, p=2.0, dim=-1)
+            if epilogue is not None:
+                sc, sh, relu = epilogue
+                out = out * sc + sh
+                out = F.relu(out) if relu else out
+            return out
         h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta)
         fuse = epilogue if not (self.root_weight or self.normalize) else None
         res = self.aggregate(h_t2s, h_s2t, csr, mask_u8, want_alpha=return_alpha, epilogue=fuse)

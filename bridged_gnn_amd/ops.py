@@ -134,6 +134,23 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     return (out, alpha) if want_alpha else out
 
 
+def adaptedconv_aggregate_bwd(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, out, alpha, grad_out, negative_slope=0.1):
+    """-> (dh_t2s, dh_s2t, da_t2s, da_s2t): gradients of the fused aggregation w.r.t. both tables and
+    both attention vectors (reference: autograd through models/KTGNN.py:292-305)."""
+    lib = L.lib()
+    dev = h_t2s.device
+    dh_t2s, dh_s2t = torch.zeros_like(h_t2s), torch.zeros_like(h_s2t)
+    da_t2s = torch.zeros(D, dtype=torch.float32, device=dev)
+    da_s2t = torch.zeros(D, dtype=torch.float32, device=dev)
+    grad_out = grad_out.contiguous()
+    rc = lib.bgnn_adaptedconv_aggregate_bwd_f32(
+        L.ptr(h_t2s), L.ptr(h_s2t), h_t2s.stride(0), L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
+        L.ptr(mask_u8), 0, csr.num_nodes, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
+        L.ptr(grad_out), grad_out.stride(0), L.ptr(dh_t2s), L.ptr(dh_s2t), L.ptr(da_t2s), L.ptr(da_s2t), L.stream())
+    L.check(rc, "bgnn_adaptedconv_aggregate_bwd_f32")
+    return dh_t2s, dh_s2t, da_t2s, da_s2t
+
+
 def l2_normalize_rows(q, eps=1e-8):
     out = torch.empty_like(q)
     rc = L.lib().bgnn_l2_normalize_rows_f32(L.ptr(q), q.shape[0], q.shape[1], float(eps), L.ptr(out), L.stream())

@@ -98,6 +98,20 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                    void* stream);
 
+/*  backward of the aggregation above -- what autograd computes through
+ * models/KTGNN.py:292-305 when main_graph_knowledge_transfer.py:39-68 calls loss.backward().
+ * Inputs: the forward's tables, `out`, `alpha` (CSR order) and grad_out = dL/dout.  Outputs are
+ * ACCUMULATED into (caller zero-fills): dh_t2s / dh_s2t [rows of the tables, ldh] and da_t2s / da_s2t [D].
+ * Source-side sums use hardware fp32 atomics (order-dependent in the last bits).               */
+int bgnn_adaptedconv_aggregate_bwd_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                       const float* a_t2s, const float* a_s2t,
+                                       const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                       int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
+                                       const float* out, int64_t ldo, const float* alpha,
+                                       const float* grad_out, int64_t ldg,
+                                       float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                       void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a2,a3,a5,a6,a7) kNN bridge: pair scoring + per-query top-k.
  *     main_bridged_graph.py:45-67 / :90-111 (batched loop), models/models.py:124-130,:944-954

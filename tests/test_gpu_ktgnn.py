@@ -161,7 +161,7 @@ def test_ktgnn_sync_c2_golden(golden):
     assert np.allclose(sums, k["sums"], rtol=1e-5)
 
 
-def test_train_mode_forward_and_grad_refusal():
+def test_train_mode_forward_runs_with_and_without_grad():
     from bridged_gnn_amd import synth
     from bridged_gnn_amd.data import Data
     from bridged_gnn_amd.ktgnn import KTGNN_no_complement
@@ -169,10 +169,11 @@ def test_train_mode_forward_and_grad_refusal():
     model = KTGNN_no_complement(16, 3, 2, 8, use_bn=True, dim_share=16).to(DEV)
     data = Data(x=torch.randn(300, 16, device=DEV), edge_index=_t(ei), central_mask=_t(mask))
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(data)                                   # autograd through the HIP path is a next-tier row
+    lb, lt, lth, _ = model(data)                      # autograd path (HIP aggregation + its HIP backward)
+    (lb.sum() + lt.sum() + lth.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     with torch.no_grad():
-        lb, lt, lth, _ = model(data)                  # train-mode forward (batch-stat BN, dropout) still runs
+        lb, lt, lth, _ = model(data)                  # train-mode forward (batch-stat BN, dropout) without grad
     assert torch.isfinite(lb).all() and lb.shape == (300, 3)
     assert torch.allclose(lb.exp().sum(1), torch.ones(300, device=DEV), atol=1e-5)
 

@@ -1,0 +1,105 @@
+"""GPU: backward of the fused aggregation -- gradients through the HIP path vs the
+CPU torch/autograd oracle (fp64), and an optimisation step of KTGNN_no_complement with the reference's loss."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("din,D,n", [(24, 16, 300), (20, 7, 257), (48, 64, 400), (32, 128, 500), (16, 2, 1000)])
+def test_adaptedconv_gradients_vs_autograd_oracle(din, D, n):
+    from bridged_gnn_amd import ops, synth
+    from bridged_gnn_amd.ktgnn import AdaptedConv
+    ei, mask = synth.random_multigraph(n, 8 * n, frac_src=0.45, n_isolated=3, seed=n + D)
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((n, din)).astype(np.float32)
+    w = rng.standard_normal((n, D)).astype(np.float32)                    # dL/dout
+    torch.manual_seed(D)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV)
+    xg = _t(x).requires_grad_(True)
+    csr = ops.build_dst_csr(_t(ei), n)
+    out = conv(xg, None, central_mask=_t(mask), csr=csr)
+    (out * _t(w)).sum().backward()
+    # oracle in fp64 on the CPU
+    p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in conv.state_dict().items()}
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    mo = torch.from_numpy(mask)
+    e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
+    oo = OT.adaptedconv(xo, mo, e1, e2, p)
+    (oo * torch.from_numpy(w).double()).sum().backward()
+    assert _rel(out.detach().cpu().double(), oo.detach()) < 2e-5
+    assert _rel(xg.grad.cpu().double(), xo.grad) < 2e-4, "dL/dx"
+    for name, prm in conv.named_parameters():
+        assert _rel(prm.grad.cpu().double(), p[name].grad) < 2e-4, name
+
+
+def test_training_steps_follow_the_autograd_oracle():
+    """3 Adam steps of the reference recipe (lr 1e-3, wd 5e-3, loss of main_graph_knowledge_transfer.py:44-54),
+    dropout off, BN in train mode: loss trajectory and final weights vs the CPU torch oracle model."""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    n, feat, hidden, C = 600, 12, 16, 3
+    ei, mask = synth.random_multigraph(n, 5000, frac_src=0.5, seed=77)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, feat)).astype(np.float32)
+    y = rng.integers(0, C, size=n)
+    train = rng.random(n) < 0.6
+    torch.manual_seed(3)
+    model = KTGNN_no_complement(feat, C, 2, hidden, use_bn=True, dim_share=feat, dropout=0.0)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    data = Data(x=_t(x), edge_index=_t(ei), y=_t(y), train_mask=_t(train), central_mask=_t(mask))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        lb, lt, lth, _ = model(data)
+        loss = OT.train_loss(lb, lt, lth, data.y, data.train_mask, data.central_mask)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    # ---- oracle: same model structure in plain CPU torch
+    class Ref(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = KTGNN_no_complement(feat, C, 2, hidden, use_bn=True, dim_share=feat, dropout=0.0)
+            self.m.load_state_dict(sd0)
+        def conv(self, c, xx, mo, e1, e2):
+            return OT.adaptedconv(xx, mo, e1, e2, dict(c.named_parameters()))
+        def forward(self, xx, mo, e1, e2):
+            m = self.m
+            h = torch.relu(m.bns[0](self.conv(m.convs[0], xx, mo, e1, e2)))
+            b = self.conv(m.clf_base, h, mo, e1, e2)
+            hat = self.conv(m.clf_target, m.clf_transformer(h), mo, e1, e2)
+            t = self.conv(m.clf_target, h, mo, e1, e2)
+            return torch.log_softmax(b, 1), torch.log_softmax(t, 1), torch.log_softmax(hat, 1)
+    ref = Ref().train()
+    mo = torch.from_numpy(mask)
+    e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
+    ropt = torch.optim.Adam(ref.m.parameters(), lr=1e-3, weight_decay=5e-3)
+    rlosses = []
+    for _ in range(3):
+        ropt.zero_grad()
+        lb, lt, lth = ref(torch.from_numpy(x), mo, e1, e2)
+        l = OT.train_loss(lb, lt, lth, torch.from_numpy(y), torch.from_numpy(train), mo)
+        l.backward()
+        ropt.step()
+        rlosses.append(l.item())
+    assert np.allclose(losses, rlosses, rtol=2e-4), (losses, rlosses)
+    assert losses[2] < losses[0]
+    for (k, v), (_, r) in zip(model.state_dict().items(), ref.m.state_dict().items()):
+        if v.dtype.is_floating_point:
+            assert torch.allclose(v.cpu(), r, rtol=2e-3, atol=2e-4), k
