@@ -20,7 +20,8 @@ from . import ops
 from .data import Data
 
 __all__ = ["BridgeScorer", "add_topk_sim_cross_domain_edges", "add_topk_sim_within_domain_edges",
-           "merge_graphs", "pair_enumeration"]
+           "merge_graphs", "pair_enumeration", "check_added_edges_cross_domain_validity",
+           "check_added_edges_within_domain_validity", "align_e_sim_to_edges"]
 
 _BN_EPS = 1e-5
 
@@ -230,3 +231,66 @@ def merge_graphs(data_src, data_tar, edge_index_cross_added, edge_index_added_sr
         test[ns:] = data_tar.test_mask.to(dev)                                 # :190
     return Data(x=torch.cat((data_src.x.to(dev), data_tar.x.to(dev)), dim=0), edge_index=edge_index,
                 y=torch.cat((ys, yt), dim=0), train_mask=train, val_mask=val, test_mask=test, central_mask=central)
+
+
+# ------------------------------------------------------------------------------------------------
+# Edge validity filters: main_bridged_graph.py:123-161 and :225-264.
+# Cheap per-edge element-wise work between top-k and merge -> plain torch ops on the GPU tensors.
+def align_e_sim_to_edges(edge_index, e_sim_mat, idx_mat):
+    """Similarity of every COALESCED edge.  The reference passes `e_sim_mat.view(-1)` (top-k order) next to the
+    coalesced (source-sorted) edge list, so its confidence filter hits the wrong edges (SURVEY Appendix B-2);
+    this looks each edge (from, to) up in the [query, k] tables instead."""
+    k = idx_mat.shape[1]
+    cand = idx_mat[edge_index[1]]                                  # [E, k] candidates of the edge's query
+    hit = cand == edge_index[0].unsqueeze(1)
+    pos = hit.float().argmax(dim=1)
+    assert bool(hit.any(dim=1).all()), "edge list does not come from these top-k tables"
+    return e_sim_mat[edge_index[1], pos]
+
+
+def _filter_report(verbose, *a):
+    if verbose:
+        print(*a)
+
+
+def check_added_edges_cross_domain_validity(edge_index_added, e_sim, data_src, data_tar, probs_clf_src, probs_clf_tar,
+                                            thres_conf_quantile=0.1, thres_feat_sim=0.0, verbose=False):
+    """main_bridged_graph.py:225-264.  `e_sim`: one similarity per edge.  Pass `align_e_sim_to_edges(...)` for the
+    intended semantics, or the reference's own `e_sim_mat.view(-1)` to reproduce its index-misaligned behaviour
+    bit for bit (same length, different order)."""
+    dev = edge_index_added.device
+    e0, e1 = edge_index_added[0], edge_index_added[1]
+    ys, yt = data_src.y.to(dev), data_tar.y.to(dev)
+    pred_s, pred_t = probs_clf_src.argmax(dim=1), probs_clf_tar.argmax(dim=1)
+    e_sim = e_sim.reshape(-1).to(dev)
+    rm = torch.zeros(edge_index_added.shape[1], dtype=torch.bool, device=dev)
+    thres = e_sim.quantile(q=thres_conf_quantile)                                  # :238
+    rm |= e_sim < thres                                                            # :239
+    _filter_report(verbose, "1. low SimNet confidence:", int(rm.sum()))
+    rm |= pred_s[e0] != ys[e0]                                                     # :243
+    rm |= (pred_t[e1] != yt[e1]) & data_tar.train_mask.to(dev)[e1]                 # :244
+    rm |= pred_s[e0] != pred_t[e1]                                                 # :248
+    cos = F.cosine_similarity(data_src.x.to(dev)[e0], data_tar.x.to(dev)[e1])      # :252
+    rm |= cos < thres_feat_sim                                                     # :253
+    _filter_report(verbose, "[Done] removed", int(rm.sum()), "of", rm.numel())
+    return edge_index_added[:, ~rm]                                                # :257
+
+
+def check_added_edges_within_domain_validity(edge_index_added, e_sim, data_in, probs_clf, thres_conf_quantile=0.1,
+                                             thres_feat_sim=0.0, verbose=False):
+    """main_bridged_graph.py:123-161 (same remark about `e_sim` alignment)."""
+    dev = edge_index_added.device
+    e0, e1 = edge_index_added[0], edge_index_added[1]
+    y = data_in.y.to(dev)
+    pred = probs_clf.argmax(dim=1)
+    e_sim = e_sim.reshape(-1).to(dev)
+    rm = torch.zeros(edge_index_added.shape[1], dtype=torch.bool, device=dev)
+    rm |= e_sim < e_sim.quantile(q=thres_conf_quantile)                            # :135-136
+    tm = data_in.train_mask.to(dev)[e1]
+    rm |= (pred[e0] != y[e0]) & tm                                                 # :140
+    rm |= (pred[e1] != y[e1]) & tm                                                 # :141
+    rm |= pred[e0] != pred[e1]                                                     # :145
+    cos = F.cosine_similarity(data_in.x.to(dev)[e0], data_in.x.to(dev)[e1])        # :149
+    rm |= cos < thres_feat_sim                                                     # :150
+    _filter_report(verbose, "[Done] removed", int(rm.sum()), "of", rm.numel())
+    return edge_index_added[:, ~rm]                                                # :154

@@ -14,6 +14,7 @@ Fixtures:
   knn_office_a2d.npz, knn_office_a2w.npz   G4(i)+G5: shipped ckpts (v2 / mlp scorer)
   knn_cosine_v1.npz      G4(ii): v1 cosine scorer (twitter ckpt) on seeded synthetic features
   knn_gauss.npz          G4(iii): raw Gaussian d=128 cosine (Similar_noTrans), Ns=20k, Nt=2k
+  filters_office_a2d.npz 8(f) rank 2: check_added_edges_{cross,within}_domain_validity in/out (office A->D)
 """
 import os
 import sys
@@ -183,6 +184,20 @@ def main():
             z_tar, _ = sim.target_learner.encode(dt)
             es, esims, eidxs = BG.add_topk_sim_within_domain_edges(ds, sim, k=3, batch_size=100, domain="source")
             et, esimt, eidxt = BG.add_topk_sim_within_domain_edges(dt, sim, k=3, batch_size=100, domain="target")
+        if tag == "a2d":
+            # [8(f) rank 2] the reference's own validity filters on its own (misaligned) inputs
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+                fc = BG.check_added_edges_cross_domain_validity(ec, esim.view(-1), ds, dt, pcs, pct,
+                                                                thres_conf_quantile=0.1, thres_feat_sim=0.8)
+                ds_w = SData(x=ds.x, y=ds.y, train_mask=dd.train_mask[:ns])
+                fw = BG.check_added_edges_within_domain_validity(es, esims.view(-1), ds_w, pcs,
+                                                                 thres_conf_quantile=0.1, thres_feat_sim=0.8)
+            save("filters_office_a2d.npz", cross_in=ec.numpy().astype(np.int32), cross_e_sim_flat=esim.view(-1).numpy(),
+                 cross_out=fc.numpy().astype(np.int32), within_in=es.numpy().astype(np.int32),
+                 within_e_sim_flat=esims.view(-1).numpy(), within_out=fw.numpy().astype(np.int32),
+                 probs_clf_src=pcs.numpy(), probs_clf_tar=pct.numpy(), train_mask_src=dd.train_mask[:ns].numpy(),
+                 train_mask_tar=dd.train_mask[ns:].numpy())
         simnet = {"sim." + k[len("source_learner.sim_net."):]: v.numpy() for k, v in sd.items()
                   if k.startswith("source_learner.sim_net.")}
         save(f"knn_office_{tag}.npz", z_src=z_src.numpy(), z_tar=z_tar.numpy(), k_cross=np.int64(k_cross),
