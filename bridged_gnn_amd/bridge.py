@@ -85,20 +85,44 @@ class BridgeScorer:
         x = F.relu(self._pairnorm(x))
         return F.linear(x, sd[prefix + "layers.1.weight"], sd[prefix + "layers.1.bias"])
 
+    def _sage_encoder(self, x, edge_index, prefix):
+        """`GraphEncoder.forward` eval mode (2 x SAGEConv, mean aggregation, root weight), models/models.py:220-263
+        (SURVEY.md 8(f) rank 3).  lin_l is linear, so W_l.mean_j(x_j) = mean_j(W_l x_j): transform first, then the
+        fused CSR kernel averages the out-width rows (uniform attention == mean; rows without in-edges give 0)."""
+        sd, dev = self.sd, self.device
+        n = x.shape[0]
+        csr = ops.build_dst_csr(edge_index.to(dev).long().contiguous(), n, rewrite_self_loops=False)
+        ones = torch.ones(n, dtype=torch.uint8, device=dev)
+        n_layers = 1 + max(int(k[len(prefix) + 6:].split(".")[0]) for k in sd if k.startswith(prefix + "convs."))
+        for i in range(n_layers):
+            pl = f"{prefix}convs.{i}."
+            D = sd[pl + "lin_l.weight"].shape[0]
+            xw = F.linear(x, sd[pl + "lin_l.weight"])                                         # [n, D]
+            tab = torch.zeros(n, ops.pad4(D), dtype=torch.float32, device=dev)
+            tab[:, :D] = xw
+            zero_a = torch.zeros(D, dtype=torch.float32, device=dev)
+            agg = ops.adaptedconv_aggregate(tab, tab, zero_a, zero_a, csr, ones, D)[:, :D]     # mean over in-edges
+            out = agg + sd[pl + "lin_l.bias"]
+            if pl + "lin_r.weight" in sd:
+                out = out + F.linear(x, sd[pl + "lin_r.weight"])                              # root weight
+            x = out if i == n_layers - 1 else F.relu(self._pairnorm(out))                     # :249-259
+        return x
+
     def encode_source(self, data):
         """z_src = source_learner.backbone(x, edge_index) (models.py:835 / :1133)."""
+        x = data.x.to(self.device).float()
         if self.version != "v2":
-            raise NotImplementedError("v1 SAGEConv encoders are a next-tier row (SURVEY.md 8(f) rank 3): pass z_src=")
-        return self._mlp_encoder(data.x.to(self.device).float(), "source_learner.backbone.")
+            return self._sage_encoder(x, data.edge_index, "source_learner.backbone.")
+        return self._mlp_encoder(x, "source_learner.backbone.")
 
     def encode_target(self, data):
         """z_tar, _ = target_learner.encode(data) (models.py:1092-1096)."""
-        if self.version != "v2":
-            raise NotImplementedError("v1 SAGEConv encoders are a next-tier row (SURVEY.md 8(f) rank 3): pass z_tar=")
         sd = self.sd
         h0 = F.linear(data.x.to(self.device).float(), sd["target_learner.equavilent_trans_layer.0.weight"],
                       sd["target_learner.equavilent_trans_layer.0.bias"])
         h0 = torch.tanh(self._pairnorm(h0))
+        if self.version != "v2":
+            return self._sage_encoder(h0, data.edge_index, "target_learner.encoder.")
         return self._mlp_encoder(h0, "target_learner.encoder.")
 
     def class_probs(self, z):

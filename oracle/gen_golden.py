@@ -14,6 +14,7 @@ Fixtures:
   knn_office_a2d.npz, knn_office_a2w.npz   G4(i)+G5: shipped ckpts (v2 / mlp scorer)
   knn_cosine_v1.npz      G4(ii): v1 cosine scorer (twitter ckpt) on seeded synthetic features
   knn_gauss.npz          G4(iii): raw Gaussian d=128 cosine (Similar_noTrans), Ns=20k, Nt=2k
+  sage_encoder_v1.npz    8(f) rank 3: v1 GraphEncoder (2x SAGEConv, mean aggr) outputs on random graphs
   filters_office_a2d.npz 8(f) rank 2: check_added_edges_{cross,within}_domain_validity in/out (office A->D)
 """
 import os
@@ -239,6 +240,23 @@ def main():
     save("knn_cosine_v1.npz", z_src=z_src.numpy(), z_tar=z_tar.numpy(), q_src=q_src.numpy(), q_tar=q_tar.numpy(),
          cross_edge_index=ec.numpy().astype(np.int32), cross_e_sim=esim.numpy(),
          cross_idx=eidx.numpy().astype(np.int32), **simnet)
+
+    # ------------------------------------------------------------------ 8(f) rank 3: v1 SAGEConv encoders
+    print("[8f-3] v1 SAGEConv encoders on random graphs (twitter ckpt)")
+    gen = torch.Generator().manual_seed(31)
+    n_s, n_t = 320, 280
+    ei_s = torch.randint(0, n_s, (2, 1500), generator=gen)
+    ei_t = torch.randint(0, n_t, (2, 900), generator=gen)
+    ei_t = ei_t[:, ei_t[1] < n_t - 5]                       # a few target nodes without in-edges
+    xs = torch.randn(n_s, F_in, generator=gen) * 0.5
+    xt = torch.randn(n_t, F_in, generator=gen) * 0.5 + 0.1
+    with torch.no_grad():
+        zs = sim.source_learner.backbone(xs, ei_s)
+        zt, _ = sim.target_learner.encode(SData(x=xt, edge_index=ei_t))
+    enc = {"sd." + k: v.numpy() for k, v in sd.items() if k.startswith(("source_learner.backbone.", "target_learner.encoder.",
+                                                                        "target_learner.equavilent_trans_layer."))}
+    save("sage_encoder_v1.npz", x_src=xs.numpy(), x_tar=xt.numpy(), ei_src=ei_s.numpy().astype(np.int32),
+         ei_tar=ei_t.numpy().astype(np.int32), z_src=zs.numpy(), z_tar=zt.numpy(), **enc)
 
     # ------------------------------------------------------------------ G4(iii) raw Gaussian cosine
     print("[G4] raw Gaussian cosine via Similar_noTrans")

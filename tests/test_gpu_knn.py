@@ -157,3 +157,17 @@ def test_c5_scale_sampled_rows_bit_exact():
     _, ri = OC.cosine_topk(qh[rows], ch, 20)
     assert np.array_equal(idx_h[rows], ri)
     assert int(nfb.item()) < 100
+
+
+def test_v1_sage_encoders_from_twitter_ckpt(golden):
+    """GraphEncoder (2 x SAGEConv mean aggregation) through the fused CSR kernel vs the reference."""
+    from bridged_gnn_amd.bridge import BridgeScorer
+    from bridged_gnn_amd.data import Data
+    f = golden("sage_encoder_v1.npz")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sd.").items()}
+    model = BridgeScorer(sd, DEV)
+    assert model.version == "v1"
+    zs = model.encode_source(Data(x=_t(f["x_src"]), edge_index=_t(f["ei_src"].astype(np.int64))))
+    zt = model.encode_target(Data(x=_t(f["x_tar"]), edge_index=_t(f["ei_tar"].astype(np.int64))))
+    assert_close(zs.cpu().numpy(), f["z_src"], rtol=2e-5, atol_scale=2e-6, what="z_src")
+    assert_close(zt.cpu().numpy(), f["z_tar"], rtol=2e-5, atol_scale=2e-6, what="z_tar")
