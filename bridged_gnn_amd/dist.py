@@ -10,10 +10,11 @@ The reference is single-process / single-device; this is new 
   * Per AdaptedConv (reference models/KTGNN.py:263-315):
       1. per-domain column sums of the local x -> ONE all-reduce of 2*Din+2 doubles -> delta (:275);
       2. local dense transform -> h_t2s / h_s2t rows of the owned nodes (:277-284);
-      3. halo exchange of the TRANSFORMED rows actually referenced by local in-edges:
-         `all_to_all_single` with uneven splits, one per feature table, received straight into the
-         tail of the local table (rows [n_local, n_local + n_halo)).  Full mesh: every peer pair uses
-         its own xGMI link, no ring;
+      3. halo exchange of the TRANSFORMED rows actually referenced by local in-edges: ONE
+         `all_to_all_single` with uneven splits per conv carrying the rows of both feature tables,
+         received straight into the tail of the per-conv allocation [h_s2t local | h_t2s local | halo]
+         (so each table sees the halo as its own continuation).  Full mesh: every peer pair uses its
+         own xGMI link, no ring;
       4. fused aggregation: interior rows (all in-neighbours local) are aggregated WHILE the halo is
          in flight, boundary rows after it lands (row-range launches of the same kernel);
       5. outputs stay partitioned; BN(eval)/ReLU/log_softmax are row-local.
@@ -87,29 +88,35 @@ class PartitionPlan:
         g2l[self.owned_global] = np.arange(self.n_local)
         self.mask_local = mask[self.owned_global]
 
-        # ---- receive side: halo numbering per table ---------------------------------------------
-        self.recv_splits, self.n_halo, halo_index = [], [], []
+        # ---- ONE combined exchange per conv.  Per-rank memory of a conv's two tables:
+        #        [ h_s2t local rows | h_t2s local rows | halo rows (peer-major; per peer: h_t2s rows, then h_s2t rows) ]
+        #      so both tables see the halo as a continuation of themselves: from the h_t2s base (row n_local) a halo
+        #      row sits at n_local + pos, from the h_s2t base (row 0) at 2*n_local + pos.  Halo/send lists are sorted
+        #      by (peer, table, global id) on both sides, identically on every rank.
+        sel = k_needer == rank                                   # rows I receive: sorted (table, owner, id) -> reorder
+        r_id, r_owner, r_table = k_id[sel], k_owner[sel], k_table[sel]
+        order = np.lexsort((r_id, r_table, r_owner))             # (owner, table, id)
+        r_id, r_owner, r_table = r_id[order], r_owner[order], r_table[order]
+        self.recv_splits = np.bincount(r_owner, minlength=world).astype(np.int64).tolist()
+        self.n_halo = int(r_id.shape[0])
+        self.n_halo_by_table = [int((r_table == 0).sum()), int((r_table == 1).sum())]
+        halo_pos = [np.full(N, -1, dtype=np.int64), np.full(N, -1, dtype=np.int64)]
+        pos = np.arange(r_id.shape[0], dtype=np.int64)
         for t in (0, 1):
-            sel = (k_needer == rank) & (k_table == t)
-            ids, owners = k_id[sel], k_owner[sel]     # already sorted by (owner, id)
-            self.recv_splits.append(np.bincount(owners, minlength=world).astype(np.int64).tolist())
-            self.n_halo.append(int(ids.shape[0]))
-            hi = np.full(N, -1, dtype=np.int64)
-            hi[ids] = self.n_local + np.arange(ids.shape[0])
-            halo_index.append(hi)
-        # ---- send side: rows of mine each peer needs, per table, ordered (peer, global id) ---------
-        self.send_splits, self.send_rows = [], []
-        for t in (0, 1):
-            sel = (k_owner == rank) & (k_table == t)
-            ids, needers = k_id[sel], k_needer[sel]
-            order = np.lexsort((ids, needers))
-            self.send_splits.append(np.bincount(needers, minlength=world).astype(np.int64).tolist())
-            self.send_rows.append(g2l[ids[order]])
+            halo_pos[t][r_id[r_table == t]] = pos[r_table == t]
+        sel = k_owner == rank                                    # rows I send: order (needer, table, id)
+        s_id, s_needer, s_table = k_id[sel], k_needer[sel], k_table[sel]
+        order = np.lexsort((s_id, s_table, s_needer))
+        s_id, s_needer, s_table = s_id[order], s_needer[order], s_table[order]
+        self.send_splits = np.bincount(s_needer, minlength=world).astype(np.int64).tolist()
+        # index into the [h_s2t local | h_t2s local] region: h_t2s (table 0) rows live at n_local + r
+        self.send_rows = g2l[s_id] + np.where(s_table == 0, self.n_local, 0)
         # ---- local CSR (stable: input order inside a row, self loop last) ---------------------------
         keep = o_dst == rank
         ls, ld, lt = src[keep], dst[keep], table[keep]
         lrow = g2l[ld]
-        lcol = np.where(owner[ls] == rank, g2l[ls], np.where(lt == 0, halo_index[0][ls], halo_index[1][ls]))
+        halo_col = np.where(lt == 0, self.n_local + halo_pos[0][ls], 2 * self.n_local + halo_pos[1][ls])
+        lcol = np.where(owner[ls] == rank, g2l[ls], halo_col)
         assert (lcol >= 0).all()
         order = np.argsort(lrow, kind="stable")
         self.col = lcol[order].astype(np.int32)
@@ -118,40 +125,41 @@ class PartitionPlan:
         self.rowptr = np.cumsum(rp).astype(np.int32)
         self.local_num_edges = int(self.col.shape[0])
 
+    def table_views(self, big):
+        """big: [2*n_local + n_halo, ld] -> (h_t2s view, h_s2t view) whose row indices match `col`."""
+        return big[self.n_local:], big
+
     def summary(self):
         return {"rank": self.rank, "n_local": self.n_local, "n_interior": self.n_interior,
-                "n_halo": self.n_halo, "local_edges": self.local_num_edges}
+                "n_halo": self.n_halo, "n_halo_by_table": self.n_halo_by_table, "local_edges": self.local_num_edges}
 
 
 class HaloExchange:
-    """Device-agnostic exchange of transformed rows (works with nccl/RCCL on GPU tensors and with gloo on
-    CPU tensors).  `start` posts both all_to_all_single ops asynchronously, `wait` blocks the current
-    stream on them; received rows land directly in table[n_local:]."""
+    """Device-agnostic exchange of transformed rows (nccl/RCCL on GPU tensors, gloo on CPU tensors): ONE
+    `all_to_all_single` with uneven splits per conv, posted asynchronously by `start`, awaited by `wait`;
+    received rows land directly in big[2*n_local:]."""
 
     def __init__(self, plan, device, group=None, always=False):
         self.plan, self.group, self.always = plan, group, always   # always: issue the collectives even at world 1
-        self.send_rows = [torch.from_numpy(r).to(device) for r in plan.send_rows]
-        self._work = []
+        self.send_rows = torch.from_numpy(plan.send_rows).to(device)
+        self._work, self._keep = None, None
 
-    def start(self, tables):
-        """tables = (h_t2s, h_s2t), each [n_local + n_halo[t], ld]; rows < n_local must be final."""
+    def start(self, big):
+        """big = [h_s2t local | h_t2s local | halo] ([2*n_local + n_halo, ld]); the local rows must be final."""
         p = self.plan
-        self._work = []
-        self._keep = []
-        for t, tab in enumerate(tables):
-            send = tab.index_select(0, self.send_rows[t])            # [sum(send_splits), ld]
-            recv = tab[p.n_local: p.n_local + p.n_halo[t]]
-            self._keep.append(send)
-            if p.world == 1 and not self.always:
-                continue
-            w = dist.all_to_all_single(recv, send, output_split_sizes=p.recv_splits[t],
-                                       input_split_sizes=p.send_splits[t], group=self.group, async_op=True)
-            self._work.append(w)
+        send = big.index_select(0, self.send_rows)                   # [sum(send_splits), ld]
+        recv = big[2 * p.n_local: 2 * p.n_local + p.n_halo]
+        self._keep = send
+        self._work = None
+        if p.world == 1 and not self.always:
+            return
+        self._work = dist.all_to_all_single(recv, send, output_split_sizes=p.recv_splits,
+                                            input_split_sizes=p.send_splits, group=self.group, async_op=True)
 
     def wait(self):
-        for w in self._work:
-            w.wait()
-        self._work, self._keep = [], []
+        if self._work is not None:
+            self._work.wait()
+        self._work, self._keep = None, None
 
 
 class PartitionedKTGNN:
@@ -183,11 +191,11 @@ class PartitionedKTGNN:
                 dist.all_reduce(sums, group=self.group)              # 2*Din+2 doubles
         delta = ops.domain_delta(sums, xp.shape[1])
         ld = ops.pad4(conv.out_channels)
-        # local rows followed by halo rows in one allocation per table; the transform writes the local part
-        h_t2s = torch.empty(p.n_local + p.n_halo[0], ld, dtype=torch.float32, device=self.device)
-        h_s2t = torch.empty(p.n_local + p.n_halo[1], ld, dtype=torch.float32, device=self.device)
-        conv.transform(x, self.mask_u8, delta=delta, out=(h_t2s, h_s2t))   # writes rows [0, n_local)
-        self.halo.start((h_t2s, h_s2t))
+        # one allocation per conv: [h_s2t local | h_t2s local | halo]; the transform writes both local parts
+        big = torch.empty(2 * p.n_local + p.n_halo, ld, dtype=torch.float32, device=self.device)
+        h_t2s, h_s2t = p.table_views(big)
+        conv.transform(x, self.mask_u8, delta=delta, out=(h_t2s, h_s2t))   # writes rows [0, n_local) of each view
+        self.halo.start(big)
         a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
         a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
@@ -220,7 +228,18 @@ class PartitionedKTGNN:
                 x, _ = self._conv(conv, x)
                 x = F.relu(x)
             x = x.contiguous()
-        base, sums = self._conv(m.clf_base, x)
-        hat, _ = self._conv(m.clf_target, m._transformer_eval(x).contiguous())
-        targ, _ = self._conv(m.clf_target, x, sums=sums)
+        # the two classifier inputs (h and T(h)) are both row-local once the hidden conv is done: their domain
+        # sums travel in ONE all-reduce
+        from . import ops
+        from .ktgnn import _pad_cols4
+        xt = m._transformer_eval(x).contiguous()
+        s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
+        s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
+        both = torch.cat((s_h, s_t))
+        if self.world > 1 or self.always:
+            dist.all_reduce(both, group=self.group)
+        s_h, s_t = both[: s_h.numel()].contiguous(), both[s_h.numel():].contiguous()
+        base, _ = self._conv(m.clf_base, x, sums=s_h)
+        hat, _ = self._conv(m.clf_target, xt, sums=s_t)
+        targ, _ = self._conv(m.clf_target, x, sums=s_h)
         return F.log_softmax(base, dim=1), F.log_softmax(targ, dim=1), F.log_softmax(hat, dim=1)

@@ -30,9 +30,23 @@ def _problem(seed=0, n_src=700, n_tar=500, D=12):
     return ei, mask, h_t2s, h_s2t, a1, a2, ref
 
 
-def _local_aggregate(plan, tabs, a1, a2):
-    return OC.adaptedconv_aggregate(tabs[0], tabs[1], a1, a2, plan.rowptr, plan.col,
-                                    np.concatenate([plan.mask_local, np.zeros(max(tabs[0].shape[0], tabs[1].shape[0]) - plan.n_local, bool)]))[: plan.n_local]
+def _aggregate_big(p, big, a1, a2):
+    """oracle aggregation over a rank's [h_s2t local | h_t2s local | halo] allocation (col indices are relative to
+    each table's base, see PartitionPlan.table_views)."""
+    h_t2s, h_s2t = big[p.n_local:], big
+    n = h_s2t.shape[0]
+    pad = np.zeros((n - h_t2s.shape[0], big.shape[1]), np.float32)
+    h_t2s = np.concatenate([h_t2s, pad])                                   # same row count for the C oracle
+    rowptr = np.concatenate([p.rowptr, np.full(n - p.n_local, p.rowptr[-1], np.int32)])
+    mask = np.concatenate([p.mask_local, np.zeros(n - p.n_local, bool)])
+    return OC.adaptedconv_aggregate(h_t2s, h_s2t, a1, a2, rowptr, p.col, mask)[: p.n_local]
+
+
+def _fill_local(p, h_t2s_full, h_s2t_full, D):
+    big = np.zeros((2 * p.n_local + p.n_halo, D), np.float32)
+    big[: p.n_local] = h_s2t_full[p.owned_global]
+    big[p.n_local: 2 * p.n_local] = h_t2s_full[p.owned_global]
+    return big
 
 
 def test_plan_world4_simulated_exchange():
@@ -42,42 +56,22 @@ def test_plan_world4_simulated_exchange():
     plans = [PartitionPlan(ei, mask, r, world) for r in range(world)]
     assert sum(p.n_local for p in plans) == mask.shape[0]
     assert sum(p.local_num_edges for p in plans) == plans[0].global_num_edges
-    full = (h_t2s, h_s2t)
+    D = ref.shape[1]
+    bigs = [_fill_local(p, h_t2s, h_s2t, D) for p in plans]
     got = np.zeros_like(ref)
     for r, p in enumerate(plans):
-        tabs = []
-        for t in (0, 1):
-            tab = np.zeros((p.n_local + p.n_halo[t], ref.shape[1]), np.float32)
-            tab[: p.n_local] = full[t][p.owned_global]
-            off = p.n_local
-            for q, pq in enumerate(plans):                     # what q sends me, in q's send order
-                s0 = sum(pq.send_splits[t][:r])
-                rows = pq.send_rows[t][s0: s0 + pq.send_splits[t][r]]
-                assert len(rows) == p.recv_splits[t][q]
-                tab[off: off + len(rows)] = full[t][pq.owned_global[rows]]
-                off += len(rows)
-            assert off == tab.shape[0]
-            tabs.append(tab)
-        # interior rows must not reference halo rows
+        off = 2 * p.n_local
+        for q, pq in enumerate(plans):                     # what q sends me, in q's send order (= all_to_all_single)
+            s0 = sum(pq.send_splits[:r])
+            rows = pq.send_rows[s0: s0 + pq.send_splits[r]]
+            assert len(rows) == p.recv_splits[q]
+            bigs[r][off: off + len(rows)] = bigs[q][rows]
+            off += len(rows)
+        assert off == bigs[r].shape[0]
         ri = p.rowptr[p.n_interior]
-        assert (p.col[:ri] < p.n_local).all()
-        m2 = p.mask_local
-        out = OC.adaptedconv_aggregate(_pad_rows(tabs[0], tabs[1])[0], _pad_rows(tabs[0], tabs[1])[1], a1, a2,
-                                       np.concatenate([p.rowptr, np.full(_extra(tabs, p), p.rowptr[-1], np.int32)]),
-                                       p.col, np.concatenate([m2, np.zeros(_extra(tabs, p), bool)]))[: p.n_local]
-        got[p.owned_global] = out
+        assert (p.col[:ri] < p.n_local).all()              # interior rows never touch the halo
+        got[p.owned_global] = _aggregate_big(p, bigs[r], a1, a2)
     assert np.array_equal(got, ref)          # same per-row arithmetic order -> bitwise equal
-
-
-def _extra(tabs, p):
-    return max(tabs[0].shape[0], tabs[1].shape[0]) - p.n_local
-
-
-def _pad_rows(a, b):
-    n = max(a.shape[0], b.shape[0])
-    pa = np.zeros((n, a.shape[1]), np.float32); pa[: a.shape[0]] = a
-    pb = np.zeros((n, b.shape[1]), np.float32); pb[: b.shape[0]] = b
-    return pa, pb
 
 
 def _worker(rank, world, port, q):
@@ -88,18 +82,11 @@ def _worker(rank, world, port, q):
         ei, mask, h_t2s, h_s2t, a1, a2, ref = _problem(seed=2)
         p = PartitionPlan(ei, mask, rank, world)
         D = ref.shape[1]
-        tabs = []
-        for t, full in enumerate((h_t2s, h_s2t)):
-            tab = torch.zeros(p.n_local + p.n_halo[t], D)
-            tab[: p.n_local] = torch.from_numpy(full[p.owned_global])
-            tabs.append(tab)
+        big = torch.from_numpy(_fill_local(p, h_t2s, h_s2t, D))
         hx = HaloExchange(p, "cpu")
-        hx.start(tabs)
+        hx.start(big)
         hx.wait()
-        pa, pb = _pad_rows(tabs[0].numpy(), tabs[1].numpy())
-        ex = _extra([pa, pb], p) if False else pa.shape[0] - p.n_local
-        out = OC.adaptedconv_aggregate(pa, pb, a1, a2, np.concatenate([p.rowptr, np.full(ex, p.rowptr[-1], np.int32)]),
-                                       p.col, np.concatenate([p.mask_local, np.zeros(ex, bool)]))[: p.n_local]
+        out = _aggregate_big(p, big.numpy(), a1, a2)
         ok = bool(np.array_equal(out, ref[p.owned_global]))
         # (1) of the per-conv protocol: per-domain sums are all-reducible
         x = np.random.default_rng(5).standard_normal((mask.shape[0], 6))
@@ -126,7 +113,7 @@ def test_halo_exchange_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
-    assert all(s["n_halo"][0] + s["n_halo"][1] > 0 for _, _, s in res)      # the exchange was exercised
+    assert all(s["n_halo"] > 0 and min(s["n_halo_by_table"]) > 0 for _, _, s in res)      # the exchange was exercised
 
 
 def test_partition_schemes():

@@ -66,26 +66,25 @@ def test_simulated_multi_rank_conv_matches_single_gpu(world):
         locs.append(ops.domain_sums(_pad_cols4(x[og]), _t(p.mask_local).to(torch.uint8)))
     sums = torch.stack(locs).sum(0)
     delta = ops.domain_delta(sums, din)
-    # (2) per-rank transform straight into [local + halo] tables
-    tabs = []
+    # (2) per-rank transform straight into the per-conv allocation [h_s2t local | h_t2s local | halo]
+    bigs = []
     for p in plans:
         og = _t(p.owned_global)
-        ld = ops.pad4(D)
-        ht2s = torch.zeros(p.n_local + p.n_halo[0], ld, device=DEV)
-        hs2t = torch.zeros(p.n_local + p.n_halo[1], ld, device=DEV)
+        big = torch.zeros(2 * p.n_local + p.n_halo, ops.pad4(D), device=DEV)
         with torch.no_grad():
-            conv.transform(x[og].contiguous(), _t(p.mask_local).to(torch.uint8), delta=delta, out=(ht2s, hs2t))
-        tabs.append((ht2s, hs2t))
+            conv.transform(x[og].contiguous(), _t(p.mask_local).to(torch.uint8), delta=delta, out=p.table_views(big))
+        bigs.append(big)
     # (3) simulated all_to_all_single: receiver r gets, peer by peer, what q's send list holds for r
     for r, p in enumerate(plans):
-        for t in (0, 1):
-            off = p.n_local
-            for q, pq in enumerate(plans):
-                s0 = sum(pq.send_splits[t][:r])
-                rows = pq.send_rows[t][s0: s0 + pq.send_splits[t][r]]
-                if len(rows):
-                    tabs[r][t][off: off + len(rows)] = tabs[q][t][_t(rows)]
-                off += len(rows)
+        off = 2 * p.n_local
+        for q, pq in enumerate(plans):
+            s0 = sum(pq.send_splits[:r])
+            rows = pq.send_rows[s0: s0 + pq.send_splits[r]]
+            assert len(rows) == p.recv_splits[q]
+            if len(rows):
+                bigs[r][off: off + len(rows)] = bigs[q][_t(rows)]
+            off += len(rows)
+        assert off == bigs[r].shape[0]
     # (4) interior then boundary aggregation per rank
     got = torch.zeros_like(ref)
     a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
@@ -93,12 +92,13 @@ def test_simulated_multi_rank_conv_matches_single_gpu(world):
     for r, p in enumerate(plans):
         lcsr = ops.DstCSR(_t(p.rowptr), _t(p.col), None, p.local_num_edges, p.n_local)
         m8 = _t(p.mask_local).to(torch.uint8)
+        h_t2s, h_s2t = p.table_views(bigs[r])
         out = torch.full((p.n_local, ops.pad4(D)), float("nan"), device=DEV)
-        ops.adaptedconv_aggregate(tabs[r][0], tabs[r][1], a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
+        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
                                   row_begin=0, row_end=p.n_interior)
         assert torch.isnan(out[p.n_interior:]).all() or p.n_interior == p.n_local     # only the range was written
-        ops.adaptedconv_aggregate(tabs[r][0], tabs[r][1], a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
+        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, lcsr, m8, D, n_dst=p.n_local, out=out,
                                   row_begin=p.n_interior, row_end=p.n_local)
         got[_t(p.owned_global)] = out[:, :D]
     assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
-    assert sum(p.n_halo[0] + p.n_halo[1] for p in plans) > 0
+    assert sum(p.n_halo for p in plans) > 0
