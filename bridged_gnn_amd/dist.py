@@ -143,6 +143,10 @@ class HaloExchange:
         self.plan, self.group, self.always = plan, group, always   # always: issue the collectives even at world 1
         self.send_rows = torch.from_numpy(plan.send_rows).to(device)
         self._work, self._keep = None, None
+        # gloo cannot move device memory: when the process group is gloo but the tables live on a GPU (debug /
+        # single-GPU multi-process rehearsals) the payload is staged through the host.  RCCL never takes this path.
+        self.host_staging = (torch.device(device).type == "cuda" and dist.is_initialized()
+                             and dist.get_backend(group) == "gloo")
 
     def start(self, big):
         """big = [h_s2t local | h_t2s local | halo] ([2*n_local + n_halo, ld]); the local rows must be final."""
@@ -152,6 +156,12 @@ class HaloExchange:
         self._keep = send
         self._work = None
         if p.world == 1 and not self.always:
+            return
+        if self.host_staging:
+            r_host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r_host, send.cpu(), output_split_sizes=p.recv_splits,
+                                   input_split_sizes=p.send_splits, group=self.group)
+            recv.copy_(r_host)
             return
         self._work = dist.all_to_all_single(recv, send, output_split_sizes=p.recv_splits,
                                             input_split_sizes=p.send_splits, group=self.group, async_op=True)
@@ -180,6 +190,14 @@ class PartitionedKTGNN:
         self.mask_u8 = self.mask_local.to(torch.uint8).contiguous()
         self.halo = HaloExchange(plan, device, group, always=always_communicate)
 
+    def _all_reduce(self, t):
+        if self.halo.host_staging:                                   # gloo rehearsal on GPU tensors (see HaloExchange)
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            return h.to(t.device)
+        dist.all_reduce(t, group=self.group)
+        return t
+
     def _conv(self, conv, x, epilogue=None, sums=None):
         from . import ops
         from .ktgnn import _pad_cols4
@@ -188,7 +206,7 @@ class PartitionedKTGNN:
         if sums is None:
             sums = ops.domain_sums(xp, self.mask_u8)
             if self.world > 1 or self.always:
-                dist.all_reduce(sums, group=self.group)              # 2*Din+2 doubles
+                sums = self._all_reduce(sums)                        # 2*Din+2 doubles
         delta = ops.domain_delta(sums, xp.shape[1])
         ld = ops.pad4(conv.out_channels)
         # one allocation per conv: [h_s2t local | h_t2s local | halo]; the transform writes both local parts
@@ -237,7 +255,7 @@ class PartitionedKTGNN:
         s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
         both = torch.cat((s_h, s_t))
         if self.world > 1 or self.always:
-            dist.all_reduce(both, group=self.group)
+            both = self._all_reduce(both)
         s_h, s_t = both[: s_h.numel()].contiguous(), both[s_h.numel():].contiguous()
         base, _ = self._conv(m.clf_base, x, sums=s_h)
         hat, _ = self._conv(m.clf_target, xt, sums=s_t)
