@@ -22,7 +22,7 @@ SIGNATURES = {
     "bgnn_domain_sums_f64": (_INT, [_P, _I64, _I32, _I64, _P, _P, _P]),
     "bgnn_domain_delta_f32": (_INT, [_P, _I32, _P, _P]),
     "bgnn_adaptedconv_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P,
-                                               _P, _P, _P, _P, _I64, _P, _P]),
+                                               _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
                                                _P, _I64, _P, _P, _P, _INT, _P]),
     "bgnn_adaptedconv_aggregate_bwd_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
@@ -69,6 +69,18 @@ def ptr(t):
                            f"(got a {t.device} tensor)")
     if not t.is_contiguous():
         raise RuntimeError("bridged_gnn_amd ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_rows(t):
+    """Device pointer of a 2-D row-strided view (unit column stride, e.g. a column slice of an interleaved table)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("bridged_gnn_amd ops need CUDA(HIP) tensors; there is no CPU path "
+                           f"(got a {t.device} tensor)")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("expected a 2-D tensor with unit column stride")
     return C.c_void_p(t.data_ptr())
 
 

@@ -123,7 +123,7 @@ struct GemmParams {
   const float* g;       // [n_heads][2][2*Din]  gate vectors (s2t, t2s), x-half first
   const float* gc;      // [n_heads][2]         delta-half constants
   float* out[MAXH][2];  // [head][table]  table 0 = h_s2t (W_t), 1 = h_t2s (W_s)
-  int64_t ldh; int32_t NC; int32_t n_heads;
+  int64_t ldh; int64_t row_stride; int32_t NC; int32_t n_heads;   // ldh = padded width of a head's row, row_stride >= ldh
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
         float4 o;
         o.x = fmaf(cf, wv.x, v.x + bv.x); o.y = fmaf(cf, wv.y, v.y + bv.y);
         o.z = fmaf(cf, wv.z, v.z + bv.z); o.w = fmaf(cf, wv.w, v.w + bv.w);
-        *reinterpret_cast<float4*>(out + row * p.ldh + cc) = o;
+        *reinterpret_cast<float4*>(out + row * p.row_stride + cc) = o;
       }
     }
   }
@@ -327,11 +327,11 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
                                               int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
                                               const float* gates,
                                               float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                                              int64_t ldh, float* small_ws, void* stream) {
+                                              int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
   if (!x || !mask || !delta || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
   if (n_heads < 1 || n_heads > MAXH || (n_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
   if (N < 0 || Din <= 0 || D <= 0 || ldx < Din || ldh < D) return BGNN_E_SHAPE;
-  if ((Din & 3) || (ldx & 3) || (ldh & 3)) return BGNN_E_SHAPE;
+  if ((Din & 3) || (ldx & 3) || (ldh & 3) || (row_stride & 3) || row_stride < ldh) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(Wp) || !bgnn_aligned16(delta) || !bgnn_aligned16(gates)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -344,7 +344,7 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
   GemmParams p;
   p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;
   p.out[0][0] = h_s2t_0; p.out[0][1] = h_t2s_0; p.out[1][0] = h_s2t_1; p.out[1][1] = h_t2s_1;
-  p.ldh = ldh; p.NC = NC; p.n_heads = n_heads;
+  p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads;
   const int64_t nrt = (N + BM - 1) / BM;
   const int64_t nrt8 = (nrt + 7) / 8 * 8;        // row tiles rounded up to the XCD group size
   if (NC <= 32) {

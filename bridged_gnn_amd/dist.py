@@ -257,7 +257,33 @@ class PartitionedKTGNN:
         if self.world > 1 or self.always:
             both = self._all_reduce(both)
         s_h, s_t = both[: s_h.numel()].contiguous(), both[s_h.numel():].contiguous()
-        base, _ = self._conv(m.clf_base, x, sums=s_h)
-        hat, _ = self._conv(m.clf_target, xt, sums=s_t)
-        targ, _ = self._conv(m.clf_target, x, sums=s_h)
+        base, targ, hat = self._classifier_stage(x, xt, s_h, s_t)
         return F.log_softmax(base, dim=1), F.log_softmax(targ, dim=1), F.log_softmax(hat, dim=1)
+
+    def _classifier_stage(self, x, xt, s_h, s_t):
+        """clf_base(x), clf_target(x), clf_target(T(x)) (KTGNN.py:432-434) with ONE halo exchange: the six narrow
+        tables are interleaved column-wise in one allocation (row = [base | target | target-hat] x pad4(C) floats),
+        so a halo row carries all three convs' values."""
+        from . import ops
+        from .ktgnn import _pad_cols4
+        m, p = self.model, self.plan
+        C = m.clf_base.out_channels
+        ld = ops.pad4(C)
+        big = torch.empty(2 * p.n_local + p.n_halo, 3 * ld, dtype=torch.float32, device=self.device)
+        views = [(big[p.n_local:, j * ld:(j + 1) * ld], big[:, j * ld:(j + 1) * ld]) for j in range(3)]   # (h_t2s, h_s2t)
+        d_h = ops.domain_delta(s_h, _pad_cols4(x).shape[1])
+        d_t = ops.domain_delta(s_t, _pad_cols4(xt).shape[1])
+        m.clf_base.transform(x, self.mask_u8, delta=d_h, partner=m.clf_target, out=[views[0], views[1]])
+        m.clf_target.transform(xt, self.mask_u8, delta=d_t, out=views[2])
+        self.halo.start(big)
+        convs = (m.clf_base, m.clf_target, m.clf_target)
+        outs = [torch.empty(p.n_local, ld, dtype=torch.float32, device=self.device) for _ in range(3)]
+        for lo, hi in ((0, p.n_interior), (p.n_interior, p.n_local)):
+            if lo == p.n_interior:
+                self.halo.wait()                                     # boundary rows need the halo
+            for j, conv in enumerate(convs):
+                a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
+                a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
+                ops.adaptedconv_aggregate(views[j][0], views[j][1], a_t2s, a_s2t, self.csr, self.mask_u8, C,
+                                          conv.negative_slope, n_dst=p.n_local, out=outs[j], row_begin=lo, row_end=hi)
+        return outs[0][:, :C], outs[1][:, :C], outs[2][:, :C]

@@ -101,13 +101,15 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
     if out is None:
         out = [(torch.empty(N, ldh, dtype=torch.float32, device=dev), torch.empty(N, ldh, dtype=torch.float32, device=dev))
                for _ in range(H)]
+    row_stride = out[0][0].stride(0)
     for a, b in out:
-        assert a.shape[0] >= N and b.shape[0] >= N and a.stride(0) == ldh and b.stride(0) == ldh
+        assert a.shape[0] >= N and b.shape[0] >= N and a.stride(0) == row_stride and b.stride(0) == row_stride
     small = torch.empty(H * (2 * ldh + 2) + 8, dtype=torch.float32, device=dev)
     o1 = out[1] if H > 1 else (None, None)
     rc = lib.bgnn_adaptedconv_transform_f32(
         L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates),
-        L.ptr(out[0][1]), L.ptr(out[0][0]), L.ptr(o1[1]), L.ptr(o1[0]), ldh, L.ptr(small), L.stream())
+        L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride,
+        L.ptr(small), L.stream())
     L.check(rc, "bgnn_adaptedconv_transform_f32")
     return out
 
@@ -127,7 +129,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
         out = torch.empty(n_dst, ldo, dtype=torch.float32, device=dev)
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
     rc = lib.bgnn_adaptedconv_aggregate_f32(
-        L.ptr(h_t2s), L.ptr(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
+        L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
         L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")

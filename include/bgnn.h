@@ -63,7 +63,9 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
  *          followed by ldh rows of lin_s.weight (torch Linear.weight layout [out, in]);
  *   bias_p [n_heads*2*ldh]      matching packed biases (zeros where absent / padded);
  *   gates  [n_heads][2][2*Din]  a_g_s2t.weight then a_g_t2s.weight per head ([x || delta] order);
- *   outputs per head have leading dimension ldh >= D, ldh % 4 == 0; pad columns come out as 0.
+ *   each output row holds ldh >= D floats (ldh % 4 == 0; columns D..ldh-1 come out as 0) and rows are
+ *   row_stride >= ldh floats apart (row_stride % 4 == 0), so several convs' tables can be interleaved in one
+ *   allocation (multi-GPU: one halo exchange then carries the rows of all of them).
  * small_ws: n_heads*(2*ldh+2) floats of scratch (W.delta and the gates' delta halves).       */
 int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
                          double* sums_io /*[2*Din+2]*/, void* stream);
@@ -73,7 +75,7 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
                                    int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
                                    const float* gates,
                                    float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                                   int64_t ldh, float* small_ws, void* stream);
+                                   int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
