@@ -36,6 +36,9 @@ struct AggParams {
   const float* ep_scale;
   const float* ep_shift;
   int ep_relu;
+  float* state_ms;   // [rows][2] running (max, sum) of a row whose edges are visited in two launches
+  int mode;          // 0: one launch; 1: first part -> leave (m, s) in state_ms and the raw accumulator in out;
+                     // 2: second part -> resume from them, then normalise + epilogue
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -78,6 +81,11 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
 
     float m = -INFINITY, s = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.mode == 2 && rvalid && sub == 0) {      // resume: sub-group 0 carries the state of the first launch
+      m = p.state_ms[2 * i];
+      s = p.state_ms[2 * i + 1];
+      if (f0 < p.ldo) acc = *reinterpret_cast<const float4*>(p.out + i * p.ldo + f0);
+    }
     const int32_t deg = end - beg;
     const int32_t niter = (deg + EP * U - 1) / (EP * U);   // uniform inside the group
 
@@ -154,6 +162,13 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       m = mn;
     }
 
+    if (p.mode == 1) {                            // first part only: park the online-softmax state
+      if (rvalid && sub == 0) {
+        if (lg == 0) { p.state_ms[2 * i] = m; p.state_ms[2 * i + 1] = s; }
+        if (f0 < p.ldo) *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = fvalid ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
     const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
     if (p.alpha != nullptr && (lg % LF) == 0) {
       for (int32_t e = beg + sub; e < end; e += EP) p.alpha[e] = __expf(p.alpha[e] - m) * inv;
@@ -215,7 +230,8 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                               float* out, int64_t ldo, float* alpha_opt,
                                               const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                              void* stream) {
+                                              float* state_ms_opt, int part, void* stream) {
+  if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
   if (row_begin < 0 || row_end < row_begin || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
   if ((ldh & 3) || (ldo & 3) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out))
@@ -223,7 +239,7 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
   if (row_end == row_begin) return 0;
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
-              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu};
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part};
   hipStream_t st = (hipStream_t)stream;
   const int nv = (D + 3) / 4;   // float4 slots per row
   // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
@@ -245,7 +261,7 @@ extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64
                                    int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,
                                    int variant, void* stream) {
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
-              out, ldo, nullptr, nullptr, nullptr, 0};
+              out, ldo, nullptr, nullptr, nullptr, 0, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   switch (variant) {
     // D = 128 (LF = 32)

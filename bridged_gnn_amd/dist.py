@@ -15,8 +15,9 @@ The reference is single-process / single-device; this is new 
          received straight into the tail of the per-conv allocation [h_s2t local | h_t2s local | halo]
          (so each table sees the halo as its own continuation).  Full mesh: every peer pair uses its
          own xGMI link, no ring;
-      4. fused aggregation: interior rows (all in-neighbours local) are aggregated WHILE the halo is
-         in flight, boundary rows after it lands (row-range launches of the same kernel);
+      4. fused aggregation in two parts: every row's LOCAL-source edges are aggregated WHILE the halo is in
+         flight (rows with remote in-neighbours park their online-softmax state: (max, sum) + raw accumulator),
+         the remote-source edges of those rows after it landed (`part` = 1 / 2 of the aggregation ABI);
       5. outputs stay partitioned; BN(eval)/ReLU/log_softmax are row-local.
   * `PartitionPlan` (pure numpy + torch index tensors, device agnostic) is the host logic and is what the
     world_size-2 gloo CPU tests exercise; `PartitionedKTGNN` is the GPU driver on top of ops.py.
@@ -124,6 +125,17 @@ class PartitionPlan:
         np.add.at(rp, lrow + 1, 1)
         self.rowptr = np.cumsum(rp).astype(np.int32)
         self.local_num_edges = int(self.col.shape[0])
+        # ---- the same rows split by where the SOURCE lives: local-source edges can be aggregated while the halo
+        #      is still in flight (online-softmax state parked per row), remote-source edges after it landed
+        srow, scol = lrow[order], lcol[order]
+        is_remote = scol >= self.n_local
+        self.rowptr_L, self.col_L = self._csr(srow[~is_remote], scol[~is_remote])
+        self.rowptr_R, self.col_R = self._csr(srow[is_remote], scol[is_remote])
+
+    def _csr(self, rows, cols):
+        rp = np.zeros(self.n_local + 1, dtype=np.int64)
+        np.add.at(rp, rows + 1, 1)
+        return np.cumsum(rp).astype(np.int32), cols.astype(np.int32)      # rows are already sorted (stable)
 
     def table_views(self, big):
         """big: [2*n_local + n_halo, ld] -> (h_t2s view, h_s2t view) whose row indices match `col`."""
@@ -184,8 +196,10 @@ class PartitionedKTGNN:
         self.plan = plan
         self.owned_global = torch.from_numpy(plan.owned_global).to(device)
         self.global_num_edges, self.local_num_edges = plan.global_num_edges, plan.local_num_edges
-        self.csr = ops.DstCSR(torch.from_numpy(plan.rowptr).to(device), torch.from_numpy(plan.col).to(device), None,
-                              plan.local_num_edges, plan.n_local)
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.csr_L = ops.DstCSR(t(plan.rowptr_L), t(plan.col_L), None, int(plan.col_L.shape[0]), plan.n_local)
+        self.csr_R = ops.DstCSR(t(plan.rowptr_R), t(plan.col_R), None, int(plan.col_R.shape[0]), plan.n_local)
+        self._states = {}
         self.mask_local = torch.from_numpy(plan.mask_local).to(device)
         self.mask_u8 = self.mask_local.to(torch.uint8).contiguous()
         self.halo = HaloExchange(plan, device, group, always=always_communicate)
@@ -197,6 +211,40 @@ class PartitionedKTGNN:
             return h.to(t.device)
         dist.all_reduce(t, group=self.group)
         return t
+
+    def _aggregate_two_part(self, tables_list, convs, outs, ep=(None, None, False)):
+        """(1) local-source edges of every row (interior rows finish, boundary rows park their state) while the
+        exchange is in flight; (2) wait; (3) remote-source edges of the boundary rows.  Lists = several convs that
+        share the exchange."""
+        from . import ops
+        p = self.plan
+        single = not isinstance(convs, (list, tuple))
+        if single:
+            tables_list, convs, outs = [tables_list], [convs], [outs]
+        sc, sh, relu = ep
+        args = []
+        for (h_t2s, h_s2t), conv in zip(tables_list, convs):
+            args.append((h_t2s, h_s2t, conv.a_f_t2s.weight.detach().reshape(-1).contiguous(),
+                         conv.a_f_s2t.weight.detach().reshape(-1).contiguous(), conv.out_channels, conv.negative_slope))
+        kw = dict(n_dst=p.n_local, ep_scale=sc, ep_shift=sh, ep_relu=relu)
+        for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
+            ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
+                                      row_begin=0, row_end=p.n_interior, **kw)
+            ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
+                                      row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=1, **kw)
+        self.halo.wait()
+        for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
+            ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_R, self.mask_u8, D, slope, out=out,
+                                      row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=2, **kw)
+
+    def _state(self, out):
+        """(max, sum) scratch of the rows parked between the two parts, one per output buffer in flight."""
+        key = out.data_ptr()
+        st = self._states.get(key)
+        if st is None or st.shape[0] < self.plan.n_local:
+            st = torch.empty(self.plan.n_local, 2, dtype=torch.float32, device=self.device)
+            self._states = {**self._states, key: st} if len(self._states) < 8 else {key: st}
+        return st
 
     def _conv(self, conv, x, epilogue=None, sums=None):
         from . import ops
@@ -218,13 +266,7 @@ class PartitionedKTGNN:
         a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
         out = torch.empty(p.n_local, ops.pad4(conv.out_channels), dtype=torch.float32, device=self.device)
-        kw = dict(n_dst=p.n_local, ep_scale=sc, ep_shift=sh, ep_relu=relu, out=out)
-        # interior rows overlap with the exchange; boundary rows need the halo
-        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr, self.mask_u8, conv.out_channels,
-                                  conv.negative_slope, row_begin=0, row_end=p.n_interior, **kw)
-        self.halo.wait()
-        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr, self.mask_u8, conv.out_channels,
-                                  conv.negative_slope, row_begin=p.n_interior, row_end=p.n_local, **kw)
+        self._aggregate_two_part((h_t2s, h_s2t), conv, out, ep=(sc, sh, relu))
         return out[:, : conv.out_channels], sums
 
     @torch.no_grad()
@@ -278,12 +320,5 @@ class PartitionedKTGNN:
         self.halo.start(big)
         convs = (m.clf_base, m.clf_target, m.clf_target)
         outs = [torch.empty(p.n_local, ld, dtype=torch.float32, device=self.device) for _ in range(3)]
-        for lo, hi in ((0, p.n_interior), (p.n_interior, p.n_local)):
-            if lo == p.n_interior:
-                self.halo.wait()                                     # boundary rows need the halo
-            for j, conv in enumerate(convs):
-                a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
-                a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
-                ops.adaptedconv_aggregate(views[j][0], views[j][1], a_t2s, a_s2t, self.csr, self.mask_u8, C,
-                                          conv.negative_slope, n_dst=p.n_local, out=outs[j], row_begin=lo, row_end=hi)
+        self._aggregate_two_part(views, list(convs), outs)
         return outs[0][:, :C], outs[1][:, :C], outs[2][:, :C]

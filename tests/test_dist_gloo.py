@@ -70,6 +70,14 @@ def test_plan_world4_simulated_exchange():
         assert off == bigs[r].shape[0]
         ri = p.rowptr[p.n_interior]
         assert (p.col[:ri] < p.n_local).all()              # interior rows never touch the halo
+        # local-source / remote-source split covers every edge exactly once, in row order
+        assert (p.col_L < p.n_local).all() and (p.col_R >= p.n_local).all()
+        assert np.array_equal(np.diff(p.rowptr_L) + np.diff(p.rowptr_R), np.diff(p.rowptr))
+        assert np.diff(p.rowptr_R)[: p.n_interior].sum() == 0 and (np.diff(p.rowptr_R)[p.n_interior:] > 0).all()
+        for i in (0, p.n_interior, p.n_local - 1):
+            full = p.col[p.rowptr[i]: p.rowptr[i + 1]]
+            parts = np.concatenate([p.col_L[p.rowptr_L[i]: p.rowptr_L[i + 1]], p.col_R[p.rowptr_R[i]: p.rowptr_R[i + 1]]])
+            assert np.array_equal(np.sort(full), np.sort(parts))
         got[p.owned_global] = _aggregate_big(p, bigs[r], a1, a2)
     assert np.array_equal(got, ref)          # same per-row arithmetic order -> bitwise equal
 
