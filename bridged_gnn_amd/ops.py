@@ -128,6 +128,8 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     if out is None:
         out = torch.empty(n_dst, ldo, dtype=torch.float32, device=dev)
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
+    if row_end <= int(row_begin):                    # empty row range (e.g. no boundary rows at world size 1)
+        return (out, alpha) if want_alpha else out
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
