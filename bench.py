@@ -31,6 +31,20 @@ def agg_bytes(E, N, D):
     return E * (4 * D + 4) + N * (8 * D + 4) + 4
 
 
+def pmc_traffic(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    are collected in separate profiler runs -- profiles/r01/README.md -- they cannot be read live here).  Only
+    reported when this run's workload is the one those passes measured."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        w = t["workload"]
+        if world == 1 and (w["nodes"], w["edges"], w["hidden"], w["graph"]) == (args.nodes, args.edges, args.hidden, args.graph):
+            return float(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,7 +263,7 @@ def main():
             "hidden_conv_edges_per_sec": e_local * world / (agg_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": f"agg_kernel<D={args.hidden}> (hidden AdaptedConv aggregation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
+                         "traffic": pmc_traffic(args, world), "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
         }
         if world == 1 and not args.no_knn:
             out["knn"] = knn_bench(args, dev)
