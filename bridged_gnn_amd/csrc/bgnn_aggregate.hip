@@ -36,6 +36,8 @@ struct AggParams {
   const float* ep_scale;
   const float* ep_shift;
   int ep_relu;
+  int32_t heads;     // H convs evaluated together: tables/out are [N, H*ldh'] interleaved, a_* are [H][D]; a (row, head)
+                     // pair is one virtual row of the kernel (ldh/ldo below are the strides of a VIRTUAL row)
   float* state_ms;   // [rows][2] running (max, sum) of a row whose edges are visited in two launches
   int mode;          // 0: one launch; 1: first part -> leave (m, s) in state_ms and the raw accumulator in out;
                      // 2: second part -> resume from them, then normalise + epilogue
@@ -56,18 +58,21 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   const int f0 = (lg % LF) * 4;          // first feature column of this lane
   const bool fvalid = f0 < p.D;          // pad lanes (LF*4 > ldh) never touch memory
 
-  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
 
   for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
-    const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
-    const bool rvalid = i < p.row_end;
-    const int64_t ic = rvalid ? i : p.row_begin;
-    const bool dom_s = p.mask[ic] != 0;
+    // virtual row = (destination node, head); heads == 1: virtual row == node
+    const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.row_end * p.heads;
+    const int64_t ic = rvalid ? i : p.row_begin * p.heads;
+    const int64_t node = ic / p.heads;
+    const int head = (int)(ic - node * p.heads);
+    const bool dom_s = p.mask[node] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
-    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
-    const int32_t beg = rvalid ? p.rowptr[ic] : 0;
-    const int32_t end = rvalid ? p.rowptr[ic + 1] : 0;
+    const float* __restrict__ av = (dom_s ? p.a_t2s : p.a_s2t) + head * p.D;
+    const int32_t beg = rvalid ? p.rowptr[node] : 0;
+    const int32_t end = rvalid ? p.rowptr[node + 1] : 0;
 
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), hi = a4;
     if (fvalid) {
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       for (int u = 0; u < U; ++u) {
         id[u] = nid[u];
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id[u] >= 0 && fvalid) v[u] = *reinterpret_cast<const float4*>(H + (int64_t)id[u] * p.ldh + f0);
+        if (id[u] >= 0 && fvalid) v[u] = *reinterpret_cast<const float4*>(H + ((int64_t)id[u] * p.heads + head) * p.ldh + f0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -213,7 +218,7 @@ int resident_blocks() {
 template <int LF, int EP, int U>
 int launch(const AggParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / (LF * EP));
-  int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
   const int64_t cap = resident_blocks<LF, EP, U>();
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;   // multiple of 8 (XCD split)
   if (grid < 8) grid = 8;
@@ -230,8 +235,9 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                               float* out, int64_t ldo, float* alpha_opt,
                                               const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                              float* state_ms_opt, int part, void* stream) {
+                                              float* state_ms_opt, int part, int32_t heads, void* stream) {
   if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
+  if (heads < 1 || heads > 8 || (heads > 1 && (alpha_opt || ep_scale_opt))) return BGNN_E_SHAPE;
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
   if (row_begin < 0 || row_end < row_begin || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
   if ((ldh & 3) || (ldo & 3) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out))
@@ -239,7 +245,7 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
   if (row_end == row_begin) return 0;
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
-              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part};
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, heads, state_ms_opt, part};
   hipStream_t st = (hipStream_t)stream;
   const int nv = (D + 3) / 4;   // float4 slots per row
   // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
@@ -261,7 +267,7 @@ extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64
                                    int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,
                                    int variant, void* stream) {
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
-              out, ldo, nullptr, nullptr, nullptr, 0, nullptr, 0};
+              out, ldo, nullptr, nullptr, nullptr, 0, 1, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   switch (variant) {
     // D = 128 (LF = 32)

@@ -200,6 +200,7 @@ class PartitionedKTGNN:
         self.csr_L = ops.DstCSR(t(plan.rowptr_L), t(plan.col_L), None, int(plan.col_L.shape[0]), plan.n_local)
         self.csr_R = ops.DstCSR(t(plan.rowptr_R), t(plan.col_R), None, int(plan.col_R.shape[0]), plan.n_local)
         self._states = {}
+        self._state3 = None
         self.mask_local = torch.from_numpy(plan.mask_local).to(device)
         self.mask_u8 = self.mask_local.to(torch.uint8).contiguous()
         self.halo = HaloExchange(plan, device, group, always=always_communicate)
@@ -319,6 +320,21 @@ class PartitionedKTGNN:
         m.clf_target.transform(xt, self.mask_u8, delta=d_t, out=views[2])
         self.halo.start(big)
         convs = (m.clf_base, m.clf_target, m.clf_target)
-        outs = [torch.empty(p.n_local, ld, dtype=torch.float32, device=self.device) for _ in range(3)]
-        self._aggregate_two_part(views, list(convs), outs)
+        a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in convs]).contiguous()
+        a_s2t = torch.stack([c.a_f_s2t.weight.detach().reshape(-1) for c in convs]).contiguous()
+        out3 = torch.empty(p.n_local, 3 * ld, dtype=torch.float32, device=self.device)
+        h_t2s, h_s2t = p.table_views(big)                            # interleaved [rows, 3*ld] tables
+        st = self._state3
+        if st is None or st.shape[0] < 3 * p.n_local:
+            st = self._state3 = torch.empty(3 * p.n_local, 2, dtype=torch.float32, device=self.device)
+        kw = dict(n_dst=p.n_local, out=out3, heads=3)
+        slope = m.clf_base.negative_slope
+        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_L, self.mask_u8, C, slope,
+                                  row_begin=0, row_end=p.n_interior, **kw)
+        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_L, self.mask_u8, C, slope,
+                                  row_begin=p.n_interior, row_end=p.n_local, state_ms=st, part=1, **kw)
+        self.halo.wait()
+        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_R, self.mask_u8, C, slope,
+                                  row_begin=p.n_interior, row_end=p.n_local, state_ms=st, part=2, **kw)
+        outs = [out3[:, j * ld:(j + 1) * ld] for j in range(3)]
         return outs[0][:, :C], outs[1][:, :C], outs[2][:, :C]

@@ -335,17 +335,29 @@ class KTGNN_no_complement(nn.Module):
         x = self._hidden(x, csr, central_mask)
         x = x.contiguous()
         mask_u8 = _as_u8(central_mask).contiguous()
-        if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled():
+        if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:
             logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr)                      # :432
             logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr)                  # :434
+            xt = self.clf_transformer(x) if self.training else self._transformer_eval(x)
+            logits_hat = self.clf_target(xt.contiguous(), None, central_mask=central_mask, csr=csr)       # :433
         else:
-            # clf_base and clf_target(x) see the same input: ONE pass over x feeds both transforms
-            (bt2s, bs2t), (tt2s, ts2t) = self.clf_base.transform(x, mask_u8, partner=self.clf_target)
+            # the three classifier convs share the graph: their six narrow tables are interleaved per node
+            # ([N, 3*pad4(C)]), clf_base/clf_target(x) come from ONE pass over x, and ONE aggregation launch walks the
+            # CSR for all three heads (in-neighbour ids and 48-B rows read once)
             C = self.clf_base.out_channels
-            logits_base = self.clf_base.aggregate(bt2s, bs2t, csr, mask_u8)[:, :C]                       # :432
-            logits_target = self.clf_target.aggregate(tt2s, ts2t, csr, mask_u8)[:, :C]                   # :434
-        xt = self.clf_transformer(x) if self.training else self._transformer_eval(x)
-        logits_hat = self.clf_target(xt.contiguous(), None, central_mask=central_mask, csr=csr)           # :433
+            ld = ops.pad4(C)
+            N = x.shape[0]
+            t2s = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
+            s2t = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
+            views = [(t2s[:, j * ld:(j + 1) * ld], s2t[:, j * ld:(j + 1) * ld]) for j in range(3)]
+            self.clf_base.transform(x, mask_u8, partner=self.clf_target, out=[views[0], views[1]])
+            xt = self._transformer_eval(x).contiguous()
+            self.clf_target.transform(xt, mask_u8, out=views[2])
+            a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])
+            a_s2t = torch.stack([c.a_f_s2t.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])
+            out3 = ops.adaptedconv_aggregate(t2s, s2t, a_t2s.contiguous(), a_s2t.contiguous(), csr, mask_u8, C,
+                                             self.clf_base.negative_slope, heads=3)
+            logits_base, logits_target, logits_hat = (out3[:, j * ld: j * ld + C] for j in range(3))    # :432,:434,:433
         return (F.log_softmax(logits_base, dim=1), F.log_softmax(logits_target, dim=1),
                 F.log_softmax(logits_hat, dim=1), None)                                                  # :435
 

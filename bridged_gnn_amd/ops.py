@@ -116,24 +116,27 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
 
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
-                          row_begin=0, row_end=None, state_ms=None, part=0):
+                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1):
     """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order.
-    Only rows [row_begin, row_end) are computed (default: all n_dst rows)."""
+    Only rows [row_begin, row_end) are computed (default: all n_dst rows).
+    heads > 1: tables are [rows, heads*pad4(D)] (heads interleaved per node), a_* are [heads, D], out is
+    [n_dst, heads*pad4(D)]: one pass over the CSR serves all heads."""
     lib = L.lib()
     n_dst = csr.num_nodes if n_dst is None else int(n_dst)
     row_end = n_dst if row_end is None else int(row_end)
-    ldh = h_t2s.stride(0)
+    ldh = h_t2s.stride(0) // heads
     ldo = pad4(D)
     dev = h_t2s.device
     if out is None:
-        out = torch.empty(n_dst, ldo, dtype=torch.float32, device=dev)
+        out = torch.empty(n_dst, heads * ldo, dtype=torch.float32, device=dev)
+    assert h_t2s.stride(0) == h_s2t.stride(0) and h_t2s.stride(0) % heads == 0 and out.stride(0) % heads == 0
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
     if row_end <= int(row_begin):                    # empty row range (e.g. no boundary rows at world size 1)
         return (out, alpha) if want_alpha else out
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
-        L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr(out), out.stride(0), L.ptr(alpha),
-        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), L.stream())
+        L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
+        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out
 
