@@ -198,6 +198,134 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   }
 }
 
+// Narrow multi-head variant (D <= 4, i.e. one float4 per head): ONE lane group walks a destination's in-edges
+// for all HEADS convs at once -- the neighbour id is read once and the HEADS x 16-B pieces of a neighbour row
+// are independent loads, so the per-edge latency chain is shared instead of repeated per head.
+template <int HEADS, int EP, int U>
+__global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
+  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / EP, sub = lane % EP;
+  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  const int64_t rs = (int64_t)HEADS * p.ldh;         // floats between consecutive nodes of a table
+  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.row_end;
+    const int64_t ic = rvalid ? i : p.row_begin;
+    const bool dom_s = p.mask[ic] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    float4 a4[HEADS], hi[HEADS], acc[HEADS];
+    float m[HEADS], s[HEADS];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      a4[h].x = av[h * p.D];
+      a4[h].y = p.D > 1 ? av[h * p.D + 1] : 0.f;
+      a4[h].z = p.D > 2 ? av[h * p.D + 2] : 0.f;
+      a4[h].w = p.D > 3 ? av[h * p.D + 3] : 0.f;
+      hi[h] = *reinterpret_cast<const float4*>(H + ic * rs + h * p.ldh);
+      acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      m[h] = -INFINITY; s[h] = 0.f;
+    }
+    if (p.mode == 2 && rvalid && sub == 0) {
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        m[h] = p.state_ms[2 * (i * HEADS + h)];
+        s[h] = p.state_ms[2 * (i * HEADS + h) + 1];
+        acc[h] = *reinterpret_cast<const float4*>(p.out + (i * HEADS + h) * p.ldo);
+      }
+    }
+    const int32_t niter = (end - beg + EP * U - 1) / (EP * U);
+    for (int32_t it = 0; it < niter; ++it) {
+      int32_t id[U];
+      float4 v[U][HEADS];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = beg + it * (EP * U) + sub + u * EP;
+        id[u] = e < end ? p.col[e] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h)
+          v[u][h] = id[u] >= 0 ? *reinterpret_cast<const float4*>(H + (int64_t)id[u] * rs + h * p.ldh) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        float lg_[U], cm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float t = a4[h].x * leaky(v[u][h].x + hi[h].x, p.slope);
+          t = fmaf(a4[h].y, leaky(v[u][h].y + hi[h].y, p.slope), t);
+          t = fmaf(a4[h].z, leaky(v[u][h].z + hi[h].z, p.slope), t);
+          t = fmaf(a4[h].w, leaky(v[u][h].w + hi[h].w, p.slope), t);
+          lg_[u] = id[u] >= 0 ? t : -INFINITY;
+          cm = fmaxf(cm, lg_[u]);
+        }
+        const float mn = fmaxf(m[h], cm);
+        const float sc = (m[h] == mn) ? 1.f : __expf(m[h] - mn);
+        s[h] *= sc;
+        acc[h].x *= sc; acc[h].y *= sc; acc[h].z *= sc; acc[h].w *= sc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float pe = (lg_[u] == -INFINITY) ? 0.f : __expf(lg_[u] - mn);
+          s[h] += pe;
+          acc[h].x = fmaf(pe, v[u][h].x, acc[h].x); acc[h].y = fmaf(pe, v[u][h].y, acc[h].y);
+          acc[h].z = fmaf(pe, v[u][h].z, acc[h].z); acc[h].w = fmaf(pe, v[u][h].w, acc[h].w);
+        }
+        m[h] = mn;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+      for (int off = 1; off < EP; off <<= 1) {
+        const float m2 = __shfl_xor(m[h], off), s2 = __shfl_xor(s[h], off);
+        float4 b;
+        b.x = __shfl_xor(acc[h].x, off); b.y = __shfl_xor(acc[h].y, off);
+        b.z = __shfl_xor(acc[h].z, off); b.w = __shfl_xor(acc[h].w, off);
+        const float mn = fmaxf(m[h], m2);
+        const float c1 = (m[h] == mn) ? 1.f : __expf(m[h] - mn), c2 = (m2 == mn) ? 1.f : __expf(m2 - mn);
+        s[h] = s[h] * c1 + s2 * c2;
+        acc[h].x = acc[h].x * c1 + b.x * c2; acc[h].y = acc[h].y * c1 + b.y * c2;
+        acc[h].z = acc[h].z * c1 + b.z * c2; acc[h].w = acc[h].w * c1 + b.w * c2;
+        m[h] = mn;
+      }
+      if (rvalid && sub == 0) {
+        float* o = p.out + (i * HEADS + h) * p.ldo;
+        if (p.mode == 1) {
+          p.state_ms[2 * (i * HEADS + h)] = m[h];
+          p.state_ms[2 * (i * HEADS + h) + 1] = s[h];
+          *reinterpret_cast<float4*>(o) = acc[h];
+        } else {
+          const float inv = 1.f / (s[h] + 1e-16f);
+          *reinterpret_cast<float4*>(o) = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+        }
+      }
+    }
+  }
+}
+
+template <int HEADS, int EP, int U>
+int launch_heads(const AggParams& p, hipStream_t st) {
+  constexpr int RPB = 4 * (64 / EP);
+  static const int cap = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_kernel<HEADS, EP, U>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu * prop.multiProcessorCount / 8 * 8;
+  }();
+  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_heads_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 // Persistent grid = exactly the blocks that are co-resident (occupancy x CUs): a larger grid would
 // leave late-starting blocks walking their strided tiles alone, long after their neighbours' rows
 // left the L2.  The hardware query is immutable, so it is cached per instantiation.
@@ -247,6 +375,8 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
               out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, heads, state_ms_opt, part};
   hipStream_t st = (hipStream_t)stream;
+  if (heads == 3 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<3, 4, 4>(p, st);   // KT-GNN's classifier stage
+  if (heads == 2 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<2, 4, 4>(p, st);
   const int nv = (D + 3) / 4;   // float4 slots per row
   // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
   // one sub-group per row with deep unrolling beats edge-parallel sub-groups except for the narrowest rows.
