@@ -36,6 +36,8 @@ struct AggParams {
   const float* ep_scale;
   const float* ep_shift;
   int ep_relu;
+  double* colsum;    // optional [2*ldo + 2]: per-domain column sums (+ node counts) of the finished output rows, i.e. the
+                     // domain sums the NEXT conv needs (KTGNN.py:275) without another pass over the activations
   int32_t heads;     // H convs evaluated together: tables/out are [N, H*ldh'] interleaved, a_* are [H][D]; a (row, head)
                      // pair is one virtual row of the kernel (ldh/ldo below are the strides of a VIRTUAL row)
   float* state_ms;   // [rows][2] running (max, sum) of a row whose edges are visited in two launches
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
 
   const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  float4 csS = make_float4(0.f, 0.f, 0.f, 0.f), csT = csS;   // column sums of this lane's finished rows, per domain
+  float cntS = 0.f, cntT = 0.f;
 
   for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
     // virtual row = (destination node, head); heads == 1: virtual row == node
@@ -194,6 +198,32 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       if (p.ep_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = o;
+      if (p.colsum != nullptr) {
+        if (dom_s) { csS.x += o.x; csS.y += o.y; csS.z += o.z; csS.w += o.w; if (lg == 0) cntS += 1.f; }
+        else       { csT.x += o.x; csT.y += o.y; csT.z += o.z; csT.w += o.w; if (lg == 0) cntT += 1.f; }
+      }
+    }
+  }
+  if (p.colsum != nullptr) {
+    // fold the row groups of the wave (lanes with equal feature slot), then the 4 waves through LDS, then one
+    // hardware fp64 atomic per (block, column, domain)
+    __shared__ float red[4][2][LF * 4 + 1];
+    float v[10] = {csS.x, csS.y, csS.z, csS.w, csT.x, csT.y, csT.z, csT.w, cntS, cntT};
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int off = GL; off < 64; off <<= 1) v[t] += __shfl_xor(v[t], off);
+    if (g == 0 && sub == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { red[wave][0][(lg % LF) * 4 + c] = v[c]; red[wave][1][(lg % LF) * 4 + c] = v[4 + c]; }
+      if (lg == 0) { red[wave][0][LF * 4] = v[8]; red[wave][1][LF * 4] = v[9]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) {
+      const int d = t / (LF * 4 + 1), c = t % (LF * 4 + 1);
+      const double sum = (double)red[0][d][c] + (double)red[1][d][c] + (double)red[2][d][c] + (double)red[3][d][c];
+      if (c == LF * 4) unsafeAtomicAdd(&p.colsum[2 * p.ldo + d], sum);
+      else if (c < p.ldo) unsafeAtomicAdd(&p.colsum[d * p.ldo + c], sum);
     }
   }
 }
@@ -363,7 +393,9 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                               float* out, int64_t ldo, float* alpha_opt,
                                               const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                              float* state_ms_opt, int part, int32_t heads, void* stream) {
+                                              float* state_ms_opt, int part, int32_t heads, double* colsum_opt,
+                                              void* stream) {
+  if (colsum_opt && (heads != 1 || part == 1)) return BGNN_E_SHAPE;
   if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
   if (heads < 1 || heads > 8 || (heads > 1 && (alpha_opt || ep_scale_opt))) return BGNN_E_SHAPE;
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
@@ -373,7 +405,7 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
   if (row_end == row_begin) return 0;
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
-              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, heads, state_ms_opt, part};
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, colsum_opt, heads, state_ms_opt, part};
   hipStream_t st = (hipStream_t)stream;
   if (heads == 3 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<3, 4, 4>(p, st);   // KT-GNN's classifier stage
   if (heads == 2 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<2, 4, 4>(p, st);
@@ -397,7 +429,7 @@ extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64
                                    int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,
                                    int variant, void* stream) {
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
-              out, ldo, nullptr, nullptr, nullptr, 0, 1, nullptr, 0};
+              out, ldo, nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   switch (variant) {
     // D = 128 (LF = 32)

@@ -155,14 +155,14 @@ class AdaptedConv(nn.Module):
                                         out=out if (out is None or partner is not None) else [out])
         return res if partner is not None else res[0]
 
-    def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None):
-        """KTGNN.py:292-305 (+ optional fused BN-eval/ReLU epilogue)."""
+    def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None, colsum=None):
+        """KTGNN.py:292-305 (+ optional fused BN-eval/ReLU epilogue; `colsum` collects the next conv's domain sums)."""
         a_t2s = self.a_f_t2s.weight.detach().reshape(-1).contiguous()
         a_s2t = self.a_f_s2t.weight.detach().reshape(-1).contiguous()
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
         return ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, self.out_channels,
                                          self.negative_slope, n_dst=n_dst, want_alpha=want_alpha,
-                                         ep_scale=sc, ep_shift=sh, ep_relu=relu)
+                                         ep_scale=sc, ep_shift=sh, ep_relu=relu, colsum=colsum)
 
     def _forward_autograd(self, x, mask, mask_u8, csr):
         """Differentiable path: dense part in torch (reference op order, KTGNN.py:275-284), fused
@@ -192,7 +192,7 @@ class AdaptedConv(nn.Module):
         return csr
 
     def forward(self, x, edge_index, edge_index1=None, edge_index2=None, central_mask=None, size=None,
-                csr=None, delta=None, epilogue=None, return_alpha=False):
+                csr=None, delta=None, epilogue=None, return_alpha=False, colsum=None):
         if isinstance(x, (tuple, list)):
             x_src, x_r = x
         else:
@@ -219,7 +219,9 @@ class AdaptedConv(nn.Module):
             return out
         h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta)
         fuse = epilogue if not (self.root_weight or self.normalize) else None
-        res = self.aggregate(h_t2s, h_s2t, csr, mask_u8, want_alpha=return_alpha, epilogue=fuse)
+        if colsum is not None and (fuse is None and epilogue is not None or self.root_weight or self.normalize):
+            raise ValueError("colsum needs the fused epilogue path")
+        res = self.aggregate(h_t2s, h_s2t, csr, mask_u8, want_alpha=return_alpha, epilogue=fuse, colsum=colsum)
         out, alpha = res if return_alpha else (res, None)
         out = out[:, : self.out_channels]
         if self.root_weight and x_r is not None:
@@ -297,20 +299,26 @@ class KTGNN_no_complement(nn.Module):
             self._csr = csr
         return csr
 
-    def _hidden(self, x, csr, central_mask):
+    def _hidden(self, x, csr, central_mask, want_sums=False):
+        """hidden stack (KTGNN.py:418-430).  With `want_sums` the last conv's epilogue also accumulates the
+        per-domain column sums of its output (= the classifier convs' domain sums) when the fused path is taken."""
+        sums = None
         for ind, conv in enumerate(self.convs):                                   # :418-430
-            if self.use_bn and not self.training:
+            last = ind == len(self.convs) - 1
+            if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters())):
                 bn = self.bns[ind]
                 sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
                 sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
-                x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True))
+                if want_sums and last and not (conv.root_weight or conv.normalize):
+                    sums = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=x.device)
+                x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums)
             else:
                 x = conv(x, None, central_mask=central_mask, csr=csr)
                 if self.use_bn:
                     x = self.bns[ind](x)
                 x = F.relu(x)
                 x = F.dropout(x, p=self.dropout, training=self.training)
-        return x
+        return (x, sums) if want_sums else x
 
     def _transformer_eval(self, x):
         """clf_transformer in eval mode with the BatchNorm folded into the first Linear (exact algebra:
@@ -332,7 +340,7 @@ class KTGNN_no_complement(nn.Module):
     def forward(self, data):
         x, central_mask = data.x, data.central_mask
         csr = self._prepare(data)
-        x = self._hidden(x, csr, central_mask)
+        x, sums_h = self._hidden(x, csr, central_mask, want_sums=True)
         x = x.contiguous()
         mask_u8 = _as_u8(central_mask).contiguous()
         if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:
@@ -350,7 +358,7 @@ class KTGNN_no_complement(nn.Module):
             t2s = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
             s2t = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
             views = [(t2s[:, j * ld:(j + 1) * ld], s2t[:, j * ld:(j + 1) * ld]) for j in range(3)]
-            self.clf_base.transform(x, mask_u8, partner=self.clf_target, out=[views[0], views[1]])
+            self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
             xt = self._transformer_eval(x).contiguous()
             self.clf_target.transform(xt, mask_u8, out=views[2])
             a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])

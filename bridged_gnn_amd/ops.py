@@ -116,7 +116,7 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
 
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
-                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1):
+                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None):
     """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order.
     Only rows [row_begin, row_end) are computed (default: all n_dst rows).
     heads > 1: tables are [rows, heads*pad4(D)] (heads interleaved per node), a_* are [heads, D], out is
@@ -136,7 +136,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
-        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.stream())
+        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.ptr(colsum), L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out
 

@@ -97,6 +97,8 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
  * heads > 1 evaluates several convs that share the graph in ONE pass (KTGNN.py:432-434: clf_base / clf_target /
  * clf_target-hat): their tables are interleaved row-wise ([rows, heads*ldh], head h of node r at (r*heads+h)*ldh),
  * a_t2s / a_s2t are [heads][D], out is [rows, heads*ldo] likewise; the in-neighbour ids are read once for all heads.
+ * colsum_opt ([2*ldo+2] doubles, accumulated: caller zero-fills) receives the per-domain column sums and node
+ * counts of the finished rows -- the `bgnn_domain_sums_f64` of the NEXT conv's input for free (heads == 1 only).
  * D <= 256; ldh % 4 == 0, ldo % 4 == 0, 16-B aligned tables; pad columns must be zero.        */
 int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                    const float* a_t2s, const float* a_s2t,
@@ -104,7 +106,8 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
                                    int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                    float* out, int64_t ldo, float* alpha_opt,
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                   float* state_ms_opt, int part, int32_t heads, void* stream);
+                                   float* state_ms_opt, int part, int32_t heads, double* colsum_opt,
+                                   void* stream);
 
 /*  backward of the aggregation above -- what autograd computes through
  * models/KTGNN.py:292-305 when main_graph_knowledge_transfer.py:39-68 calls loss.backward().
