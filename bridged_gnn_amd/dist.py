@@ -213,7 +213,7 @@ class PartitionedKTGNN:
         dist.all_reduce(t, group=self.group)
         return t
 
-    def _aggregate_two_part(self, tables_list, convs, outs, ep=(None, None, False)):
+    def _aggregate_two_part(self, tables_list, convs, outs, ep=(None, None, False), colsum=None):
         """(1) local-source edges of every row (interior rows finish, boundary rows park their state) while the
         exchange is in flight; (2) wait; (3) remote-source edges of the boundary rows.  Lists = several convs that
         share the exchange."""
@@ -230,13 +230,14 @@ class PartitionedKTGNN:
         kw = dict(n_dst=p.n_local, ep_scale=sc, ep_shift=sh, ep_relu=relu)
         for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
             ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
-                                      row_begin=0, row_end=p.n_interior, **kw)
+                                      row_begin=0, row_end=p.n_interior, colsum=colsum, **kw)
             ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
                                       row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=1, **kw)
         self.halo.wait()
         for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
             ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_R, self.mask_u8, D, slope, out=out,
-                                      row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=2, **kw)
+                                      row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=2,
+                                      colsum=colsum, **kw)
 
     def _state(self, out):
         """(max, sum) scratch of the rows parked between the two parts, one per output buffer in flight."""
@@ -247,7 +248,7 @@ class PartitionedKTGNN:
             self._states = {**self._states, key: st} if len(self._states) < 8 else {key: st}
         return st
 
-    def _conv(self, conv, x, epilogue=None, sums=None):
+    def _conv(self, conv, x, epilogue=None, sums=None, out_sums=None):
         from . import ops
         from .ktgnn import _pad_cols4
         p = self.plan
@@ -267,7 +268,7 @@ class PartitionedKTGNN:
         a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
         out = torch.empty(p.n_local, ops.pad4(conv.out_channels), dtype=torch.float32, device=self.device)
-        self._aggregate_two_part((h_t2s, h_s2t), conv, out, ep=(sc, sh, relu))
+        self._aggregate_two_part((h_t2s, h_s2t), conv, out, ep=(sc, sh, relu), colsum=out_sums)
         return out[:, : conv.out_channels], sums
 
     @torch.no_grad()
@@ -278,13 +279,17 @@ class PartitionedKTGNN:
         m = self.model
         if m.training:
             raise NotImplementedError("partitioned forward is eval-only (BN batch statistics would need an all-reduce)")
+        from . import ops
         x = x_local.float().contiguous()
+        s_h = None
         for ind, conv in enumerate(m.convs):
             if m.use_bn:
                 bn = m.bns[ind]
                 sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
                 sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
-                x, _ = self._conv(conv, x, epilogue=(sc, sh, True))
+                last = ind == len(m.convs) - 1
+                s_h = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=self.device) if last else None
+                x, _ = self._conv(conv, x, epilogue=(sc, sh, True), out_sums=s_h)   # epilogue also sums the finished rows
             else:
                 x, _ = self._conv(conv, x)
                 x = F.relu(x)
@@ -294,7 +299,8 @@ class PartitionedKTGNN:
         from . import ops
         from .ktgnn import _pad_cols4
         xt = m._transformer_eval(x).contiguous()
-        s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
+        if s_h is None:
+            s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
         s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
         both = torch.cat((s_h, s_t))
         if self.world > 1 or self.always:
