@@ -97,6 +97,7 @@ __global__ void domain_delta_kernel(const double* __restrict__ sums, int32_t Din
 // wd[j] = Wp[j] . delta (j < NC) ; gc[h*2+t] = g[h][t][Din:] . delta
 __global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, int32_t NC, int32_t Din,
                                                  const float* __restrict__ delta, const float* __restrict__ g,
+                                                 const float* __restrict__ gate_const,
                                                  int32_t n_heads, float* __restrict__ wd, float* __restrict__ gc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = NC + 2 * n_heads;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, i
     float acc = 0.f;
     for (int c = lane; c < Din; c += 64) acc = fmaf(row[c], delta[c], acc);
     acc = bgnn::group_sum<64>(acc);
-    if (lane == 0) { if (j < NC) wd[j] = acc; else gc[j - NC] = acc; }
+    if (lane == 0) { if (j < NC) wd[j] = acc; else gc[j - NC] = acc + (gate_const ? gate_const[j - NC] : 0.f); }
   }
 }
 
@@ -325,7 +326,7 @@ extern "C" int bgnn_domain_delta_f32(const double* sums, int32_t Din, float* del
 extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                               const uint8_t* mask, const float* delta,
                                               int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
-                                              const float* gates,
+                                              const float* gates, const float* gate_const_opt,
                                               float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                                               int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
   if (!x || !mask || !delta || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
@@ -339,7 +340,7 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
   float* wd = small_ws;            // [NC]
   float* gc = small_ws + NC;       // [n_heads*2]
   hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((NC + 2 * n_heads + 3) / 4)), dim3(256), 0, st, Wp, NC, Din, delta, gates,
-                     n_heads, wd, gc);
+                     gate_const_opt, n_heads, wd, gc);
   BGNN_LAUNCH_CHECK();
   GemmParams p;
   p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;

@@ -320,9 +320,8 @@ class KTGNN_no_complement(nn.Module):
                 x = F.dropout(x, p=self.dropout, training=self.training)
         return (x, sums) if want_sums else x
 
-    def _transformer_eval(self, x):
-        """clf_transformer in eval mode with the BatchNorm folded into the first Linear (exact algebra:
-        BN(Wx+b) = (s*W)x + (s*b + t)); the ReLU rides in the GEMM epilogue when torch offers it."""
+    def _transformer_hidden_eval(self, x):
+        """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded, ReLU in the GEMM epilogue when available)."""
         l0, bn, _, l3 = self.clf_transformer
         key = tuple((p.data_ptr(), p._version) for p in self.clf_transformer.parameters()) + \
             (bn.running_mean._version, bn.running_var._version)
@@ -331,11 +330,39 @@ class KTGNN_no_complement(nn.Module):
             self._tf_w0t = (l0.weight.detach() * s[:, None]).t().contiguous()
             self._tf_b0 = (l0.bias.detach() * s + bn.bias.detach() - bn.running_mean * s).contiguous()
             self._tf_key = key
+            self._tf_pack = None
         if hasattr(torch, "_addmm_activation"):
-            h = torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
-        else:
-            h = F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
-        return F.linear(h, l3.weight, l3.bias)
+            return torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
+        return F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
+
+    def _composed_target_pack(self, din_pad):
+        """clf_target evaluated on x' = h1.W3^T + b3 without materialising x' (the last Linear of clf_transformer is
+        affine): W x' + b = (W W3) h1 + (W b3 + b); [x' || d'].g = h1.(W3^T g_x) + b3.g_x + d.(W3^T g_d) with d the
+        domain-mean difference of h1 (d' = W3 d).  Packed once per weight version."""
+        c, l3 = self.clf_target, self.clf_transformer[3]
+        key = (din_pad, c._versions(), l3.weight._version, l3.bias._version, l3.weight.data_ptr())
+        if getattr(self, "_tf_pack", None) is None or self._tf_pack[0] != key:
+            W3, b3 = l3.weight.detach(), l3.bias.detach()
+            hd = c.head()
+            din = W3.shape[0]
+
+            def comp_gate(g):
+                g = g.reshape(-1)
+                return torch.cat((W3.t() @ g[:din], W3.t() @ g[din:])), float((b3 * g[:din]).sum().item())
+            g1, c1 = comp_gate(hd["g_s2t"])
+            g2, c2 = comp_gate(hd["g_t2s"])
+            head = {"W_s": hd["W_s"] @ W3, "W_t": hd["W_t"] @ W3,
+                    "b_s": hd["W_s"] @ b3 + (hd["b_s"] if hd["b_s"] is not None else 0),
+                    "b_t": hd["W_t"] @ b3 + (hd["b_t"] if hd["b_t"] is not None else 0),
+                    "g_s2t": g1, "g_t2s": g2, "gate_const": (c1, c2)}
+            self._tf_pack = (key, ops.pack_transform_heads([head], din_pad))
+        return self._tf_pack[1]
+
+    def _transformer_eval(self, x):
+        """clf_transformer in eval mode (BatchNorm folded into the first Linear -- exact algebra:
+        BN(Wx+b) = (s*W)x + (s*b + t))."""
+        l3 = self.clf_transformer[3]
+        return F.linear(self._transformer_hidden_eval(x), l3.weight, l3.bias)
 
     def forward(self, data):
         x, central_mask = data.x, data.central_mask
@@ -359,8 +386,12 @@ class KTGNN_no_complement(nn.Module):
             s2t = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
             views = [(t2s[:, j * ld:(j + 1) * ld], s2t[:, j * ld:(j + 1) * ld]) for j in range(3)]
             self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
-            xt = self._transformer_eval(x).contiguous()
-            self.clf_target.transform(xt, mask_u8, out=views[2])
+            # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
+            # h1 = relu(BN(Linear0(x))) is materialised
+            h1 = self._transformer_hidden_eval(x)
+            h1p = _pad_cols4(h1)
+            d1 = ops.domain_delta(ops.domain_sums(h1p, mask_u8), h1p.shape[1])
+            ops.adaptedconv_transform(h1p, mask_u8, d1, self._composed_target_pack(h1p.shape[1]), out=[views[2]])
             a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])
             a_s2t = torch.stack([c.a_f_s2t.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])
             out3 = ops.adaptedconv_aggregate(t2s, s2t, a_t2s.contiguous(), a_s2t.contiguous(), csr, mask_u8, C,

@@ -65,7 +65,8 @@ def domain_delta(sums, Din):
 def pack_transform_heads(heads, din_pad):
     """Pack 1-2 convs that share an input for `adaptedconv_transform`.  `heads` = list of dicts with
     W_s, b_s, W_t, b_t ([D, Din] / [D] or None) and g_s2t, g_t2s ([2*Din], [x || delta] order).
-    -> (Wp [H*2*ldh, din_pad], bias_p [H*2*ldh], gates [H, 2, 2*din_pad], D, ldh)."""
+    Optional per head: "gate_const" = (c_s2t, c_t2s) added to the gate pre-activations.
+    -> (Wp [H*2*ldh, din_pad], bias_p [H*2*ldh], gates [H, 2, 2*din_pad], D, ldh, gate_const [H, 2])."""
     D = heads[0]["W_s"].shape[0]
     din = heads[0]["W_s"].shape[1]
     ldh = pad4(D)
@@ -74,7 +75,10 @@ def pack_transform_heads(heads, din_pad):
     Wp = torch.zeros(H * 2 * ldh, din_pad, dtype=torch.float32, device=dev)
     bp = torch.zeros(H * 2 * ldh, dtype=torch.float32, device=dev)
     gates = torch.zeros(H, 2, 2 * din_pad, dtype=torch.float32, device=dev)
+    gconst = torch.zeros(H, 2, dtype=torch.float32, device=dev)
     for h, hd in enumerate(heads):
+        if hd.get("gate_const") is not None:
+            gconst[h, 0], gconst[h, 1] = hd["gate_const"]
         base = h * 2 * ldh
         Wp[base: base + D, :din] = hd["W_t"]
         Wp[base + ldh: base + ldh + D, :din] = hd["W_s"]
@@ -86,7 +90,7 @@ def pack_transform_heads(heads, din_pad):
             g = hd[key].reshape(-1)
             gates[h, t, :din] = g[:din]
             gates[h, t, din_pad: din_pad + din] = g[din:]
-    return Wp, bp, gates, D, ldh
+    return Wp, bp, gates, D, ldh, gconst
 
 
 def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
@@ -94,7 +98,7 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
     zero).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
     (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows)."""
     lib = L.lib()
-    Wp, bp, gates, D, ldh = packed
+    Wp, bp, gates, D, ldh, gconst = packed
     H = gates.shape[0]
     N, Din = x.shape
     dev = x.device
@@ -107,7 +111,7 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
     small = torch.empty(H * (2 * ldh + 2) + 8, dtype=torch.float32, device=dev)
     o1 = out[1] if H > 1 else (None, None)
     rc = lib.bgnn_adaptedconv_transform_f32(
-        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates),
+        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates), L.ptr(gconst),
         L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride,
         L.ptr(small), L.stream())
     L.check(rc, "bgnn_adaptedconv_transform_f32")

@@ -63,6 +63,9 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
  *          followed by ldh rows of lin_s.weight (torch Linear.weight layout [out, in]);
  *   bias_p [n_heads*2*ldh]      matching packed biases (zeros where absent / padded);
  *   gates  [n_heads][2][2*Din]  a_g_s2t.weight then a_g_t2s.weight per head ([x || delta] order);
+ *   gate_const_opt [n_heads][2] constants added to the gates' pre-activations (NULL = 0).  Together with composed
+ *          weights this evaluates a conv on x' = x.M^T + c WITHOUT materialising x' (KTGNN.py:433: clf_target on
+ *          clf_transformer's last Linear): W x' + b = (W M) x + (W c + b), [x'||delta'].g = x.(M^T g_x) + c.g_x + delta.(M^T g_d);
  *   each output row holds ldh >= D floats (ldh % 4 == 0; columns D..ldh-1 come out as 0) and rows are
  *   row_stride >= ldh floats apart (row_stride % 4 == 0), so several convs' tables can be interleaved in one
  *   allocation (multi-GPU: one halo exchange then carries the rows of all of them).
@@ -73,7 +76,7 @@ int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* 
 int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                    const uint8_t* mask, const float* delta,
                                    int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
-                                   const float* gates,
+                                   const float* gates, const float* gate_const_opt,
                                    float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                                    int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
 
