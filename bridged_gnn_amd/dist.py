@@ -298,7 +298,7 @@ class PartitionedKTGNN:
         # sums travel in ONE all-reduce
         from . import ops
         from .ktgnn import _pad_cols4
-        xt = m._transformer_eval(x).contiguous()
+        xt = m._transformer_hidden_eval(x).contiguous()   # h1; T's last Linear is folded into the conv weights
         if s_h is None:
             s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
         s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
@@ -310,7 +310,8 @@ class PartitionedKTGNN:
         return F.log_softmax(base, dim=1), F.log_softmax(targ, dim=1), F.log_softmax(hat, dim=1)
 
     def _classifier_stage(self, x, xt, s_h, s_t):
-        """clf_base(x), clf_target(x), clf_target(T(x)) (KTGNN.py:432-434) with ONE halo exchange: the six narrow
+        """clf_base(x), clf_target(x), clf_target(T(x)) (KTGNN.py:432-434; `xt` = hidden activation h1 of T, whose
+        last Linear is folded into the packed weights) with ONE halo exchange: the six narrow
         tables are interleaved column-wise in one allocation (row = [base | target | target-hat] x pad4(C) floats),
         so a halo row carries all three convs' values."""
         from . import ops
@@ -323,7 +324,8 @@ class PartitionedKTGNN:
         d_h = ops.domain_delta(s_h, _pad_cols4(x).shape[1])
         d_t = ops.domain_delta(s_t, _pad_cols4(xt).shape[1])
         m.clf_base.transform(x, self.mask_u8, delta=d_h, partner=m.clf_target, out=[views[0], views[1]])
-        m.clf_target.transform(xt, self.mask_u8, delta=d_t, out=views[2])
+        xtp = _pad_cols4(xt)
+        ops.adaptedconv_transform(xtp, self.mask_u8, d_t, m._composed_target_pack(xtp.shape[1]), out=[views[2]])
         self.halo.start(big)
         convs = (m.clf_base, m.clf_target, m.clf_target)
         a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in convs]).contiguous()
