@@ -136,25 +136,37 @@ def cpu_baseline(args):
             "sample": f"same generator at N={n} nodes / E'={E} edges (1/10 scale), 1 eval forward, median of 3: {t:.3f} s"}
 
 
-def knn_bench(args, dev):
+def knn_bench(args, dev, rank=0, world=1):
+    """C5: cosine kNN bridge.  N>1: query rows are sharded over the ranks (candidates replicated, no collective in
+    the data path -- SURVEY 8(e)); the job time is the max over ranks."""
     from bridged_gnn_amd import ops, synth
     n = args.knn_n
-    q = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=0)).to(dev)
+    q_all = synth.gaussian_embeddings(n, 128, seed=0)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    q = torch.from_numpy(q_all[lo:hi]).to(dev)
     c = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=1)).to(dev)
     ts = []
     for it in range(4):
+        if world > 1:
+            torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         qn, cn = ops.l2_normalize_rows(q), ops.l2_normalize_rows(c)
         idx, val, nfb = ops.cosine_topk(qn, cn, 20)
-        ei = ops.coalesce(ops.topk_edges(idx))
+        ei = ops.coalesce(ops.topk_edges(idx, cand_base=0, query_base=lo))
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        ts.append(dt)
     t = float(np.median(ts[1:]))
     pairs = float(n) * float(n)
-    return {"workload": f"C5 cosine kNN {n}x{n} d=128 k=20 (normalise + score + top-k + coalesce)",
-            "pairs_per_s": pairs / t, "ms": t * 1e3, "fallback_rows": int(nfb.item()), "edges": int(ei.shape[1]),
-            "mfma_fp32_frac": (pairs * 256 / t) / 157.3e12}
+    return {"workload": f"C5 cosine kNN {n}x{n} d=128 k=20 (normalise + score + top-k + coalesce)"
+                        + (f", query rows sharded x{world}" if world > 1 else ""),
+            "pairs_per_s": pairs / t, "ms": t * 1e3, "fallback_rows": int(nfb.item()), "edges_this_rank": int(ei.shape[1]),
+            "mfma_fp32_frac": (pairs * 256 / t) / (157.3e12 * world)}
 
 
 def main():
@@ -248,6 +260,7 @@ def main():
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
     agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
 
+    knn = knn_bench(args, dev, rank, world) if not args.no_knn else None     # every rank takes part when N > 1
     if rank == 0:
         n_local = N if not use_dist else len(pk.owned_global)
         e_local = Eprime if not use_dist else pk.local_num_edges
@@ -265,8 +278,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args, world), "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
         }
-        if world == 1 and not args.no_knn:
-            out["knn"] = knn_bench(args, dev)
+        if knn is not None:
+            out["knn"] = knn
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -208,3 +208,23 @@ def test_full_size_uniform_attention_is_segment_mean():
         acc = torch.zeros(n, 128, device=DEV).index_add_(0, dst[sel], H[src[sel]])
         ref = acc[rows] / deg[rows].unsqueeze(1)
         assert torch.allclose(out[rows], ref, rtol=1e-5, atol=1e-5)
+
+
+def test_degree_skew_hub_rows():
+    """a few hub destinations with tens of thousands of in-edges (and a hub source) next to degree-1 rows."""
+    from bridged_gnn_amd import ops
+    n, D = 60_000, 64
+    rng = np.random.default_rng(1)
+    hub_in = np.stack([rng.integers(0, n, 50_000), np.full(50_000, 7)])            # 50k edges into node 7
+    hub_in2 = np.stack([rng.integers(0, n, 20_000), np.full(20_000, n - 3)])       # 20k into a target-domain node
+    hub_out = np.stack([np.full(30_000, 11), rng.integers(0, n, 30_000)])          # node 11 feeds 30k rows
+    ei = np.concatenate([hub_in, hub_in2, hub_out, rng.integers(0, n, (2, 100_000))], axis=1).astype(np.int64)
+    mask = np.arange(n) < n // 2
+    hS = rng.standard_normal((n, D)).astype(np.float32)
+    hT = rng.standard_normal((n, D)).astype(np.float32)
+    a1, a2 = rng.standard_normal(D).astype(np.float32), rng.standard_normal(D).astype(np.float32)
+    csr = ops.build_dst_csr(_t(ei), n)
+    out = ops.adaptedconv_aggregate(_t(hS), _t(hT), _t(a1), _t(a2), csr, _t(mask).to(torch.uint8), D)
+    rowptr, col, _ = O.dst_csr(ei, mask)
+    ref = OC.adaptedconv_aggregate(hS, hT, a1, a2, rowptr, col, mask)
+    assert_close(out.cpu().numpy(), ref, rtol=1e-5, atol_scale=2e-6, what="hub rows")
