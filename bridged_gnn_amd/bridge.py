@@ -21,7 +21,8 @@ from .data import Data
 
 __all__ = ["BridgeScorer", "add_topk_sim_cross_domain_edges", "add_topk_sim_within_domain_edges",
            "merge_graphs", "pair_enumeration", "check_added_edges_cross_domain_validity",
-           "check_added_edges_within_domain_validity", "align_e_sim_to_edges"]
+           "check_added_edges_within_domain_validity", "align_e_sim_to_edges", "reorder", "eval_bridged_Graph",
+           "eval_homophily", "gen_bridged_graph"]
 
 _BN_EPS = 1e-5
 
@@ -318,3 +319,101 @@ def check_added_edges_within_domain_validity(edge_index_added, e_sim, data_in, p
     rm |= cos < thres_feat_sim                                                     # :150
     _filter_report(verbose, "[Done] removed", int(rm.sum()), "of", rm.numel())
     return edge_index_added[:, ~rm]                                                # :154
+
+
+# ------------------------------------------------------------------------------------------------
+# Graph assembly tail of step 1: reorder / diagnostics / the gen_bridged_graph pipeline.
+def _as_index(mapper, n):
+    """orig-id -> local-index mapping given as a dict (reference `dataset_conversion`, utils.py:58-63) or as a
+    LongTensor of the original ids in local order; returns the LongTensor form."""
+    if isinstance(mapper, dict):
+        out = torch.empty(n, dtype=torch.int64)
+        for orig, loc in mapper.items():
+            out[loc] = orig
+        return out
+    return torch.as_tensor(mapper, dtype=torch.int64)
+
+
+def reorder(data_merge, data_src, mapper_idx_src, mapper_idx_tar):
+    """main_bridged_graph.py:195-222 without the per-edge Python loop (:221): put the merged graph back into the
+    node order of the original dataset.  Original ids must be a permutation of 0..N-1 (as in the reference)."""
+    n_src = data_src.x.shape[0] if hasattr(data_src, "x") else int(data_src)
+    dev = data_merge.x.device
+    n = data_merge.x.shape[0]
+    orig_of_merged = torch.cat([_as_index(mapper_idx_src, n_src), _as_index(mapper_idx_tar, n - n_src)]).to(dev)
+    assert bool((torch.sort(orig_of_merged).values == torch.arange(n, device=dev)).all()), "ids must be a permutation"
+    merged_of_orig = torch.empty_like(orig_of_merged)
+    merged_of_orig[orig_of_merged] = torch.arange(n, device=dev)                  # reorder_idxs (:209)
+    for key in ("train_mask", "val_mask", "test_mask", "central_mask", "x", "y"):   # :211-216
+        if hasattr(data_merge, key):
+            setattr(data_merge, key, getattr(data_merge, key)[merged_of_orig])
+    data_merge.edge_index = orig_of_merged[data_merge.edge_index]                 # :221
+    return data_merge
+
+
+def eval_bridged_Graph(data_merge, verbose=False):
+    """utils.py:101-113: share of test nodes whose labelled in-neighbourhood is majority same-label."""
+    y, ei = data_merge.y, data_merge.edge_index
+    n = y.shape[0]
+    C = int(y.max().item()) + 1
+    onehot = F.one_hot(y + 1, C + 1).float()[:, 1:]                               # unlabeled (-1) -> zero row
+    lbl = torch.zeros(n, C, device=y.device).index_add_(0, ei[1], onehot[ei[0]])  # adj_t @ y_onehot
+    deg = lbl.sum(1)
+    ok = (deg != 0) & (y != -1)
+    deg = torch.where(ok, deg, deg + 1e-3)
+    local = (lbl * onehot).sum(1) / deg
+    tm = data_merge.test_mask
+    ratio = (local[tm] > 0.5).sum() / tm.sum()
+    if verbose:
+        print(ratio)
+    return ratio
+
+
+def eval_homophily(data, second_order=False, verbose=False):
+    """utils.py:115-131: labelled-edge homophily; the 2-hop variant uses a sparse product instead of the reference's
+    dense N x N matrix (:121) and is therefore optional."""
+    y, ei = data.y, data.edge_index
+
+    def ratio(e):
+        lab = (y[e[0]] != -1) & (y[e[1]] != -1)
+        return ((y[e[0]] == y[e[1]]) & lab).sum() / lab.sum()
+    r1 = ratio(ei)
+    r2 = None
+    if second_order:
+        n = y.shape[0]
+        A = torch.sparse_coo_tensor(ei, torch.ones(ei.shape[1], device=ei.device), (n, n)).coalesce()
+        r2 = ratio(torch.sparse.mm(A, A).coalesce().indices())
+    if verbose:
+        print("homophily ratio:", float(r1), "" if r2 is None else f"2nd: {float(r2)}")
+    return (r1, r2) if second_order else r1
+
+
+def gen_bridged_graph(data_src, data_tar, model, k_cross=20, k_within=6, check_cross=False, check_within=False,
+                      thres_conf_quantile=0.1, thres_feat_sim=0.8, mapper_idx_src=None, mapper_idx_tar=None,
+                      save_path=None, reference_filter_quirk=False, verbose=False):
+    """main_bridged_graph.py:267-321 after the model is loaded: top-k cross edges (+ filter), top-k within edges per
+    domain (+ filter; the reference hard-codes quantile 0.1 / feature threshold 0.8 there, :302-306), merge, reorder,
+    save.  `reference_filter_quirk=True` feeds the filters the top-k-ordered similarity vector like the reference."""
+    z_src, z_tar = model.encode_source(data_src), model.encode_target(data_tar)
+    ec, esim, eidx, pcs, pct = add_topk_sim_cross_domain_edges(data_src, data_tar, model, k=k_cross, z_src=z_src, z_tar=z_tar,
+                                                               verbose=verbose)
+    if check_cross:
+        es = esim.reshape(-1) if reference_filter_quirk else align_e_sim_to_edges(ec, esim, eidx)
+        ec = check_added_edges_cross_domain_validity(ec, es, data_src, data_tar, pcs, pct, thres_conf_quantile,
+                                                     thres_feat_sim, verbose)
+    e_s = e_t = None
+    if k_within > 0:
+        e_s, sim_s, idx_s = add_topk_sim_within_domain_edges(data_src, model, k=k_within, domain="source", z=z_src, verbose=verbose)
+        e_t, sim_t, idx_t = add_topk_sim_within_domain_edges(data_tar, model, k=k_within, domain="target", z=z_tar, verbose=verbose)
+        if check_within:
+            a = sim_s.reshape(-1) if reference_filter_quirk else align_e_sim_to_edges(e_s, sim_s, idx_s)
+            b = sim_t.reshape(-1) if reference_filter_quirk else align_e_sim_to_edges(e_t, sim_t, idx_t)
+            e_s = check_added_edges_within_domain_validity(e_s, a, data_src, pcs, 0.1, 0.8, verbose)
+            e_t = check_added_edges_within_domain_validity(e_t, b, data_tar, pct, 0.1, 0.8, verbose)
+    merged = merge_graphs(data_src, data_tar, ec, e_s, e_t)
+    if mapper_idx_src is not None:
+        merged = reorder(merged, data_src, mapper_idx_src, mapper_idx_tar)
+    if save_path is not None:
+        from .data import save_bridged_graph
+        save_bridged_graph(merged, save_path)
+    return merged

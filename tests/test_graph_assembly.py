@@ -1,0 +1,86 @@
+"""reorder / eval diagnostics (device-agnostic torch code; CPU here) and, on the GPU, the whole
+step-1 pipeline `gen_bridged_graph` on the shipped office embeddings followed by the KT-GNN forward on its output."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+
+
+def test_reorder_matches_the_reference_loop_semantics():
+    from bridged_gnn_amd.bridge import reorder
+    from bridged_gnn_amd.data import Data
+    rng = np.random.default_rng(0)
+    n_src, n_tar = 5, 4
+    orig = rng.permutation(n_src + n_tar)
+    map_src = {int(orig[i]): i for i in range(n_src)}                 # orig id -> local idx (utils.py:58-63)
+    map_tar = {int(orig[n_src + j]): j for j in range(n_tar)}
+    x = torch.arange((n_src + n_tar) * 2, dtype=torch.float32).view(-1, 2)
+    ei = torch.tensor(rng.integers(0, n_src + n_tar, (2, 12)))
+    cm = torch.zeros(n_src + n_tar, dtype=torch.bool); cm[:n_src] = True
+    d = Data(x=x.clone(), edge_index=ei.clone(), y=torch.arange(n_src + n_tar), central_mask=cm.clone(),
+             train_mask=cm.clone(), val_mask=~cm, test_mask=~cm)
+    out = reorder(d, n_src, map_src, map_tar)
+    # reference semantics (main_bridged_graph.py:199-221): node with merged index m gets original id inverse[m]
+    inverse = {**{v: k for k, v in map_src.items()}, **{v + n_src: k for k, v in map_tar.items()}}
+    for m in range(n_src + n_tar):
+        assert torch.equal(out.x[inverse[m]], x[m]) and bool(out.central_mask[inverse[m]]) == bool(cm[m])
+    exp = torch.tensor([[inverse[int(a)] for a in ei[0]], [inverse[int(b)] for b in ei[1]]])
+    assert torch.equal(out.edge_index, exp)
+
+
+def test_eval_diagnostics_small_example():
+    from bridged_gnn_amd.bridge import eval_bridged_Graph, eval_homophily
+    from bridged_gnn_amd.data import Data
+    y = torch.tensor([0, 0, 1, 1, -1, 0])
+    ei = torch.tensor([[0, 1, 2, 3, 4, 0, 2], [1, 0, 3, 2, 0, 5, 5]])
+    d = Data(x=torch.zeros(6, 1), edge_index=ei, y=y, test_mask=torch.tensor([0, 0, 0, 0, 0, 1], dtype=torch.bool))
+    r1, r2 = eval_homophily(d, second_order=True)
+    assert abs(float(r1) - 5 / 6) < 1e-6           # labelled edges: (0,1),(1,0),(2,3),(3,2),(0,5) same, (2,5) differs
+    assert r2 is not None
+    assert float(eval_bridged_Graph(d)) == 0.0     # node 5: in-neighbours 0 (same) and 2 (other): 0.5 is not > 0.5
+
+
+@pytest.mark.gpu
+def test_gen_bridged_graph_pipeline_on_office_embeddings(tmp_path):
+    from bridged_gnn_amd import load_bridged_graph
+    from bridged_gnn_amd.bridge import BridgeScorer, gen_bridged_graph, eval_bridged_Graph
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    dev = "cuda:0"
+    f, g, fl = load_golden("knn_office_a2d.npz"), load_golden("office_a2d_graph.npz"), load_golden("filters_office_a2d.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ns = 2817
+    sd = {"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sim.").items()}
+    model = BridgeScorer(sd, dev)
+    model.encode_source = lambda d: t(f["z_src"])          # encoder weights are not part of the fixture: use the
+    model.encode_target = lambda d: t(f["z_tar"])          # reference's stored embeddings
+    y = t(g["y"])
+    loops = lambda n: torch.arange(n, device=dev).unsqueeze(0).repeat(2, 1)
+    ds = Data(x=t(g["x"][:ns]), edge_index=loops(ns), y=y[:ns], train_mask=t(fl["train_mask_src"]))
+    dt = Data(x=t(g["x"][ns:]), edge_index=loops(591), y=y[ns:], train_mask=t(fl["train_mask_tar"]),
+              val_mask=t(g["val_mask"][ns:]), test_mask=t(g["test_mask"][ns:]))
+    path = str(tmp_path / "office_bridged_graph.dat")
+    merged = gen_bridged_graph(ds, dt, model, k_cross=20, k_within=3, check_cross=True, check_within=True,
+                               thres_feat_sim=0.8, save_path=path)
+    n = ns + 591
+    assert merged.x.shape == (n, 256) and int(merged.central_mask.sum()) == ns
+    e = merged.edge_index.cpu().numpy()
+    assert (np.diff(e[0] * n + e[1]) > 0).all()                              # coalesced
+    cross = e[:, (e[0] < ns) & (e[1] >= ns)]
+    assert 0 < cross.shape[1] <= 591 * 20 and ((e[0] >= ns) & (e[1] < ns)).sum() == 0     # bridge edges are s -> t only
+    # surviving cross edges are a subset of the unfiltered top-k edges
+    full = set(map(tuple, f["cross_edge_index"].T + np.array([0, ns])))
+    assert set(map(tuple, cross.T)) <= full
+    assert 0.0 <= float(eval_bridged_Graph(merged)) <= 1.0
+    back = load_bridged_graph(path)
+    assert torch.equal(back.edge_index, merged.edge_index.cpu()) and torch.equal(back.central_mask, merged.central_mask.cpu())
+    # step 2 on the result (main_graph_knowledge_transfer.py:399-411)
+    data = back.to(dev)
+    data.train_mask[data.y == -1] = False
+    data.to_undirected_()
+    torch.manual_seed(0)
+    net = KTGNN_no_complement(256, 31, 2, 64, use_bn=True, dim_share=256).to(dev).eval()
+    with torch.no_grad():
+        lb, lt, lth, _ = net(data)
+    assert lb.shape == (n, 31) and torch.isfinite(lb).all() and torch.isfinite(lth).all()
