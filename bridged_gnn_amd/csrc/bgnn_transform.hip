@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+#if !defined(GEMM_EXP) || GEMM_EXP != 1
     if (kt + 1 < nk) sstore(cur ^ 1);            // tile kt+1 (in registers since the previous compute phase)
     if (kt + 2 < nk) gload((kt + 2) * BK);       // tile kt+2 flies during this compute phase
+#endif
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       float4 af[TM], bf[TN];
