@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
     if (kt + 1 < nk) sstore(cur ^ 1);            // tile kt+1 (in registers since the previous compute phase)
     if (kt + 2 < nk) gload((kt + 2) * BK);       // tile kt+2 flies during this compute phase
 #endif
+#if defined(GEMM_EXP) && GEMM_EXP == 3
+    if (p.N < 0)
+#endif
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       float4 af[TM], bf[TN];
@@ -294,7 +297,11 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
         float4 o;
         o.x = fmaf(cf, wv.x, v.x + bv.x); o.y = fmaf(cf, wv.y, v.y + bv.y);
         o.z = fmaf(cf, wv.z, v.z + bv.z); o.w = fmaf(cf, wv.w, v.w + bv.w);
+#if defined(GEMM_EXP) && GEMM_EXP == 2
+        if (o.x == 12345.678f) *reinterpret_cast<float4*>(out + row * p.row_stride + cc) = o;   // timing experiment: no stores
+#else
         *reinterpret_cast<float4*>(out + row * p.row_stride + cc) = o;
+#endif
       }
     }
   }
