@@ -458,6 +458,106 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
 #endif
 }
 
+// pass 1, cosine, "ping-pong" form: 8 waves per block (256 queries), one block per CU.  Waves w and w+4 share a
+// SIMD; the two halves of the block alternate roles every phase -- while one half runs its 64-MFMA chain on the
+// tile, the other half does the shortlist upkeep of its previous tile -- so the matrix pipe of every SIMD always has
+// exactly one wave feeding it and the VALU/LDS bookkeeping hides behind the partner's MFMAs (two independent
+// blocks per CU were observed to run their MFMA chains and their bookkeeping in lockstep instead: no overlap).
+//   phase 2t  : half A: MFMA(tile t)   | half B: offer(tile t-1)      | all: issue global loads of tile t+1
+//   phase 2t+1: half A: offer(tile t)  | half B: MFMA(tile t)         | all: store tile t+1 into the free LDS buffer
+template <int DK, int CAPV, int KPV>
+__global__ __launch_bounds__(512) void cosine_pass1_pp_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
+                                                              int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
+                                                              float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  typedef WaveTopK<CAPV, KPV> TK;
+  constexpr int D = DK * 8, LD = D + 4, NW = 8, QB = NW * QPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* stage = reinterpret_cast<float*>(smem);                           // [2][CT][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool halfB = wave >= 4;
+  const int64_t ntiles = (Nc + CT - 1) / CT;
+  const int64_t nqb = (Nq + QB - 1) / QB;
+  const int64_t T = nqb * ntiles;
+  int64_t t = (int64_t)blockIdx.x * tpb;
+  const int64_t t_end = min(T, t + tpb);
+  TK tk;
+  tk.carve(smem + sizeof(float) * 2 * CT * LD + (size_t)wave * TK::BYTES);
+
+  constexpr int F4_PER_ROW = D / 4;
+  constexpr int NLD = (CT * F4_PER_ROW + 511) / 512;
+  float4 pre[NLD];
+  auto gload = [&](int64_t ct) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + 512 * j;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      const int64_t gc = ct * CT + r;
+      pre[j] = (f < CT * F4_PER_ROW && gc < Nc) ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + 512 * j;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      if (f < CT * F4_PER_ROW) *reinterpret_cast<float4*>(&stage[(buf * CT + r) * LD + c4 * 4]) = pre[j];
+    }
+  };
+  const int fr = lane & 31, fh = lane >> 5;
+
+  while (t < t_end) {                               // block-uniform: one segment per query block touched
+    const int64_t qb = t / ntiles, ct0 = t % ntiles;
+    const int64_t nt = min(ntiles - ct0, t_end - t); // tiles of this segment
+    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
+    const int64_t q0 = qb * QB + wave * QPW;
+    tk.init(lane);
+    float4 bq[DK];
+    {
+      const int64_t gq = q0 + fr;
+#pragma unroll
+      for (int kb = 0; kb < DK; ++kb)
+        bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float tau = -INFINITY;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();                                 // previous segment is done with both stage buffers
+    gload(ct0);
+    sstore(0);
+    __syncthreads();
+    for (int64_t ph = 0; ph <= 2 * nt; ++ph) {       // half B lags half A by one phase
+      const int64_t ti = ph >> 1;                    // tile index (relative) half A works on in an even phase
+      const bool odd = ph & 1;
+      // staging for everybody: even phase -> fetch tile ti+1; odd phase -> park it in the buffer nobody reads
+      if (!odd) { if (ti + 1 < nt) gload(ct0 + ti + 1); }
+      else      { if (ti + 1 < nt) sstore((int)((ti + 1) & 1)); }
+      // which tile (if any) does this wave multiply / offer in this phase?
+      const int64_t mt = halfB ? (odd ? ti : -1) : (odd ? -1 : ti);                 // MFMA tile
+      const int64_t ot = halfB ? (odd ? -1 : ti - 1) : (odd ? ti : -1);             // offer tile
+      if (mt >= 0 && mt < nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = &stage[((int)(mt & 1) * CT + fr) * LD + fh * 4];
+#pragma unroll
+        for (int kb = 0; kb < DK; ++kb) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
+        }
+      }
+      if (ot >= 0 && ot < nt)
+        offer_tile(tk, acc, (int)((ct0 + ot) * CT), Nc, lane, tau, (ot % DRAIN_EVERY) == DRAIN_EVERY - 1);
+      __syncthreads();
+    }
+    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
+    t += nt;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1, mlp (Similar_v2 'mlp' in separable eval form, H = 128): fp32 VALU scoring, same shortlist.
 constexpr int MLP_H = 128;
@@ -701,8 +801,8 @@ struct Pass1Plan {
   int64_t nblocks, tpb;
   int nslots;
 };
-static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks) {
-  const int64_t ntiles = (Nc + CT - 1) / CT, nqb = (Nq + QPB - 1) / QPB, T = ntiles * nqb;
+static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int qpb = QPB) {
+  const int64_t ntiles = (Nc + CT - 1) / CT, nqb = (Nq + qpb - 1) / qpb, T = ntiles * nqb;
   Pass1Plan pl;
   pl.nblocks = T < resident_blocks ? T : resident_blocks;
   if (pl.nblocks < 1) pl.nblocks = 1;
@@ -717,7 +817,11 @@ static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks) {
 constexpr int64_t RESIDENT_MAX = 1024;
 static int worst_slots(int64_t Nq, int64_t Nc) {
   int m = 2;
-  for (int64_t rb = 1; rb <= RESIDENT_MAX; rb *= 2) { const int s = plan_pass1(Nq, Nc, rb).nslots; if (s > m) m = s; }
+  for (int64_t rb = 1; rb <= RESIDENT_MAX; rb *= 2) {
+    const int s1 = plan_pass1(Nq, Nc, rb).nslots, s2 = plan_pass1(Nq, Nc, rb, 2 * QPB).nslots;
+    if (s1 > m) m = s1;
+    if (s2 > m) m = s2;
+  }
   return m;
 }
 
@@ -772,35 +876,46 @@ template <int DK, int CAPV, int KPV>
 static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, const TopkWs& w, int* nslots_out,
                                hipStream_t st) {
   constexpr int D = DK * 8, LD = D + 4;
+  hipError_t e;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+  // ping-pong form (8 waves, 256 queries per block, one block per CU) when its LDS footprint fits
+  constexpr size_t sh_pp = sizeof(float) * 2 * CT * LD + 8 * WaveTopK<CAPV, KPV>::BYTES;
+#ifndef KNN_NO_PINGPONG
+  if (sh_pp <= 160 * 1024) {
+    auto kern = cosine_pass1_pp_kernel<DK, CAPV, KPV>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_pp);
+    if (attr != hipSuccess) return (int)attr;
+    const Pass1Plan pl = plan_pass1(Nq, Nc, prop.multiProcessorCount, 2 * QPB);
+    *nslots_out = pl.nslots;
+    if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)pl.nblocks), dim3(512), sh_pp, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
+    BGNN_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   const size_t sh = sizeof(float) * CT * LD + WAVES * WaveTopK<CAPV, KPV>::BYTES;
   auto kern = cosine_pass1_kernel<DK, CAPV, KPV>;
   // immutable per (instantiation, device): how many blocks are co-resident.  The occupancy API prices LDS
   // against 64 KB per CU on ROCm 7.2 and answers 1 here; gfx950 has 160 KB per CU, and this kernel's
   // <= 256 VGPRs allow two waves per SIMD, so the residency is computed from those two budgets.
   static const int resident = [&] {
-    int dev = 0;
-    hipDeviceProp_t prop;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return -1;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) != hipSuccess) return -1;
     int per_cu = (int)((160 * 1024) / sh);          // the kernel has no static LDS
     const int by_regs = fa.numRegs > 0 ? 512 / ((fa.numRegs + 7) / 8 * 8) : 1;     // waves per SIMD = blocks per CU (4 waves)
     if (per_cu > by_regs) per_cu = by_regs;
-    if (per_cu > 2) per_cu = 2;                    // two waves per SIMD already cover each other's VALU phases
+    if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     const int r = per_cu * prop.multiProcessorCount;
     return r > (int)RESIDENT_MAX ? (int)RESIDENT_MAX : r;
   }();
   if (resident < 1) return (int)hipErrorInvalidValue;
   const Pass1Plan pl = plan_pass1(Nq, Nc, resident);
-#if defined(KNN_EXP)
-  { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
-    fprintf(stderr, "[knn] resident=%d nblocks=%lld tpb=%lld nslots=%d sh=%zu numRegs=%d static=%zu\n", resident, (long long)pl.nblocks, (long long)pl.tpb, pl.nslots, sh, fa.numRegs, (size_t)fa.sharedSizeBytes); }
-#endif
   *nslots_out = pl.nslots;
-  hipError_t e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st);   // every slot starts empty (-1)
-  if (e != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;   // every slot starts empty (-1)
   hipLaunchKernelGGL(kern, dim3((unsigned)pl.nblocks), dim3(256), sh, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
   BGNN_LAUNCH_CHECK();
   return 0;
