@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
 #endif
 }
 
+// (EXPERIMENT, compiled in but only launched with -DKNN_PINGPONG: slower than the default on MI355X)
 // pass 1, cosine, "ping-pong" form: 8 waves per block (256 queries), one block per CU.  Waves w and w+4 share a
 // SIMD; the two halves of the block alternate roles every phase -- while one half runs its 64-MFMA chain on the
 // tile, the other half does the shortlist upkeep of its previous tile -- so the matrix pipe of every SIMD always has
@@ -882,7 +883,7 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
   // ping-pong form (8 waves, 256 queries per block, one block per CU) when its LDS footprint fits
   constexpr size_t sh_pp = sizeof(float) * 2 * CT * LD + 8 * WaveTopK<CAPV, KPV>::BYTES;
-#ifndef KNN_NO_PINGPONG
+#ifdef KNN_PINGPONG   // measured 29.4 ms vs 24.6 ms for the two-independent-blocks form on C5: kept for experiments only
   if (sh_pp <= 160 * 1024) {
     auto kern = cosine_pass1_pp_kernel<DK, CAPV, KPV>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_pp);
