@@ -882,8 +882,8 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
   // ping-pong form (8 waves, 256 queries per block, one block per CU) when its LDS footprint fits
-  constexpr size_t sh_pp = sizeof(float) * 2 * CT * LD + 8 * WaveTopK<CAPV, KPV>::BYTES;
 #ifdef KNN_PINGPONG   // measured 29.4 ms vs 24.6 ms for the two-independent-blocks form on C5: kept for experiments only
+  constexpr size_t sh_pp = sizeof(float) * 2 * CT * LD + 8 * WaveTopK<CAPV, KPV>::BYTES;
   if (sh_pp <= 160 * 1024) {
     auto kern = cosine_pass1_pp_kernel<DK, CAPV, KPV>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_pp);
