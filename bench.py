@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--knn-n", type=int, default=100_000)
+    ap.add_argument("--train-steps", type=int, default=0, help="also time this many training steps (fwd+bwd+Adam, reference loss)")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned (RCCL) code path even at world size 1")
     return ap.parse_args()
 
@@ -260,6 +261,34 @@ def main():
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
     agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
 
+    train = None
+    if args.train_steps > 0 and not use_dist:
+        # one optimisation step = train-mode forward (dropout, batch-stat BN) + HIP backward + Adam
+        import torch.nn.functional as F
+        model.train()
+        y = torch.randint(0, args.classes, (N,), device=dev, generator=gen)
+        tm = torch.rand(N, device=dev, generator=gen) < 0.5
+        cm = data.central_mask
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-3)
+
+        def step():
+            opt.zero_grad()
+            lb, lt, lth, _ = model(data)
+            tmt = tm & ~cm
+            loss = (2 * F.nll_loss(lb[tm], y[tm]) + F.nll_loss(lt[tmt], y[tmt]) + F.nll_loss(lth[tmt], y[tmt])) / 4 \
+                + F.kl_div(lth, lt, log_target=True, reduction="batchmean")
+            loss.backward()
+            opt.step()
+            return loss
+        step(); step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            step()
+        torch.cuda.synchronize()
+        train = {"ms_per_train_step": (time.perf_counter() - t0) / args.train_steps * 1e3, "steps": args.train_steps,
+                 "what": "train-mode forward + backward (HIP aggregation backward, atomics) + Adam on C4"}
+        model.eval()
     knn = knn_bench(args, dev, rank, world) if not args.no_knn else None     # every rank takes part when N > 1
     if rank == 0:
         n_local = N if not use_dist else len(pk.owned_global)
@@ -280,6 +309,8 @@ def main():
         }
         if knn is not None:
             out["knn"] = knn
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
