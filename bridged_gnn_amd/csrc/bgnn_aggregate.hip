@@ -62,8 +62,12 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
 
   const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  float4 csS = make_float4(0.f, 0.f, 0.f, 0.f), csT = csS;   // column sums of this lane's finished rows, per domain
-  float cntS = 0.f, cntT = 0.f;
+  // per-block column sums of the finished rows (per domain) live in LDS so the hot loop keeps its register budget
+  __shared__ float red[2][LF * 4 + 1];
+  if (p.colsum != nullptr) {
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) (&red[0][0])[t] = 0.f;
+    __syncthreads();
+  }
 
   for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
     // virtual row = (destination node, head); heads == 1: virtual row == node
@@ -199,29 +203,19 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = o;
       if (p.colsum != nullptr) {
-        if (dom_s) { csS.x += o.x; csS.y += o.y; csS.z += o.z; csS.w += o.w; if (lg == 0) cntS += 1.f; }
-        else       { csT.x += o.x; csT.y += o.y; csT.z += o.z; csT.w += o.w; if (lg == 0) cntT += 1.f; }
+        float* r = red[dom_s ? 0 : 1];
+        unsafeAtomicAdd(&r[f0], o.x); unsafeAtomicAdd(&r[f0 + 1], o.y);     // ds_add_f32, no return value
+        unsafeAtomicAdd(&r[f0 + 2], o.z); unsafeAtomicAdd(&r[f0 + 3], o.w);
+        if (lg == 0) unsafeAtomicAdd(&r[LF * 4], 1.f);
       }
     }
   }
   if (p.colsum != nullptr) {
-    // fold the row groups of the wave (lanes with equal feature slot), then the 4 waves through LDS, then one
-    // hardware fp64 atomic per (block, column, domain)
-    __shared__ float red[4][2][LF * 4 + 1];
-    float v[10] = {csS.x, csS.y, csS.z, csS.w, csT.x, csT.y, csT.z, csT.w, cntS, cntT};
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-      for (int off = GL; off < 64; off <<= 1) v[t] += __shfl_xor(v[t], off);
-    if (g == 0 && sub == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { red[wave][0][(lg % LF) * 4 + c] = v[c]; red[wave][1][(lg % LF) * 4 + c] = v[4 + c]; }
-      if (lg == 0) { red[wave][0][LF * 4] = v[8]; red[wave][1][LF * 4] = v[9]; }
-    }
+    // one hardware fp64 atomic per (block, column, domain)
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) {
       const int d = t / (LF * 4 + 1), c = t % (LF * 4 + 1);
-      const double sum = (double)red[0][d][c] + (double)red[1][d][c] + (double)red[2][d][c] + (double)red[3][d][c];
+      const double sum = (double)red[d][c];
       if (c == LF * 4) unsafeAtomicAdd(&p.colsum[2 * p.ldo + d], sum);
       else if (c < p.ldo) unsafeAtomicAdd(&p.colsum[d * p.ldo + c], sum);
     }
