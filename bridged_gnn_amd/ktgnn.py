@@ -367,7 +367,9 @@ class KTGNN_no_complement(nn.Module):
     def forward(self, data):
         x, central_mask = data.x, data.central_mask
         csr = self._prepare(data)
-        x, sums_h = self._hidden(x, csr, central_mask, want_sums=True)
+        # (the aggregation epilogue can also collect the next conv's domain sums -- `colsum`; measured neutral on MI355X:
+        #  +0.19 ms in the HBM-bound kernel vs 0.19 ms for the separate streaming pass -- so it stays off here)
+        x, sums_h = self._hidden(x, csr, central_mask, want_sums=False), None
         x = x.contiguous()
         mask_u8 = _as_u8(central_mask).contiguous()
         if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:
