@@ -42,6 +42,10 @@ def lib():
     """Load libbgnn_hip.so; raises (loudly) when it has not been built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(SO_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+            # building the HIP library is not a fallback: same kernels, compiled where they were missing
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "-s"], check=False)
         if not os.path.exists(SO_PATH):
             raise RuntimeError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
