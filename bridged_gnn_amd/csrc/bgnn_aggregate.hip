@@ -15,6 +15,10 @@
 // rows (which share in-neighbours in a bridged / kNN graph) hit the same XCD's L2.
 #include "bgnn_common.h"
 
+#if defined(BGNN_TUNING)
+__device__ unsigned int g_tile_ctr[8];     // tuning build only: per-XCD dynamic tile queue (experiment)
+#endif
+
 namespace {
 
 struct AggParams {
@@ -69,7 +73,18 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
     __syncthreads();
   }
 
+#if defined(BGNN_TUNING) && defined(AGG_DYN)
+  __shared__ unsigned int dyn_tile;
+  const int64_t xbase = tr.begin - (blockIdx.x / 8);        // first tile of this XCD's range
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) dyn_tile = atomicAdd(&g_tile_ctr[blockIdx.x % 8], 1u);
+    __syncthreads();
+    const int64_t tile = xbase + dyn_tile;
+    if (tile >= tr.end) break;
+#else
   for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+#endif
     // virtual row = (destination node, head); heads == 1: virtual row == node
     const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end * p.heads;
@@ -418,6 +433,10 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
 #ifdef BGNN_TUNING
 // Tuning-only entry (compiled into tools/libbgnn_tune.so, never into libbgnn_hip.so): run one explicit
 // (LF, EP, U) instantiation so a sweep can pick the dispatch table above from measurements.
+extern "C" int bgnn_tune_reset_counters(void* stream) {
+  unsigned int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tile_ctr), z, sizeof(z), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+}
 extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64_t ldh, const float* a_t2s,
                                    const float* a_s2t, const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
                                    int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bridged_gnn_amd import ops, synth  # noqa: E402
 
-lib = C.CDLL(os.path.join(ROOT, "tools", "libbgnn_tune.so"))
+lib = C.CDLL(os.path.join(ROOT, "tools", os.environ.get("TUNE_LIB", "libbgnn_tune.so")))
 P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 lib.bgnn_tune_aggregate.restype = C.c_int
 lib.bgnn_tune_aggregate.argtypes = [P, P, I64, P, P, P, P, P, I64, I64, I32, F32, P, I64, C.c_int, P]
@@ -35,6 +35,7 @@ def run(graph, D, variants, n=1_000_000):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for v in variants:
         def call():
+            lib.bgnn_tune_reset_counters(None)
             rc = lib.bgnn_tune_aggregate(hS.data_ptr(), hT.data_ptr(), ld, a1.data_ptr(), a2.data_ptr(), csr.rowptr.data_ptr(),
                                          csr.col.data_ptr(), m8.data_ptr(), 0, n, D, 0.1, out.data_ptr(), ld, v, st)
             assert rc == 0, rc
@@ -56,9 +57,13 @@ def run(graph, D, variants, n=1_000_000):
 
 if __name__ == "__main__":
     allres = {}
-    for graph in ("local", "uniform"):
-        allres[f"{graph}_D128"] = run(graph, 128, [0, 1, 2, 3, 4, 5])
-        allres[f"{graph}_D2"] = run(graph, 2, [10, 11, 12, 13, 14, 15, 16, 17])
-    allres["local_D64"] = run("local", 64, [20, 21, 22, 23])
-    allres["local_D31"] = run("local", 31, [30, 31, 32, 33])
+    if os.environ.get("TUNE_QUICK"):
+        allres["local_D128"] = run("local", 128, [0, 4])
+        allres["uniform_D128"] = run("uniform", 128, [0])
+    else:
+        for graph in ("local", "uniform"):
+            allres[f"{graph}_D128"] = run(graph, 128, [0, 1, 2, 3, 4, 5])
+            allres[f"{graph}_D2"] = run(graph, 2, [10, 11, 12, 13, 14, 15, 16, 17])
+        allres["local_D64"] = run("local", 64, [20, 21, 22, 23])
+        allres["local_D31"] = run("local", 31, [30, 31, 32, 33])
     json.dump(allres, open(os.path.join(ROOT, "gpurun_out", "tune_agg.json"), "w"), indent=1)
