@@ -118,6 +118,18 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
     return out
 
 
+_TILE_QUEUES = {}
+
+
+def _tile_queue(dev):
+    """8 x uint32 scratch per (device, stream) for the aggregation kernel's per-XCD dynamic tile counters."""
+    key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
+    q = _TILE_QUEUES.get(key)
+    if q is None:
+        q = _TILE_QUEUES[key] = torch.zeros(8, dtype=torch.int32, device=dev)
+    return q
+
+
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
                           row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None):
@@ -140,7 +152,8 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
-        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.ptr(colsum), L.stream())
+        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.ptr(colsum),
+        L.ptr(_tile_queue(dev)) if heads == 1 else None, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out
 

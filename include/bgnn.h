@@ -102,6 +102,8 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
  * a_t2s / a_s2t are [heads][D], out is [rows, heads*ldo] likewise; the in-neighbour ids are read once for all heads.
  * colsum_opt ([2*ldo+2] doubles, accumulated: caller zero-fills) receives the per-domain column sums and node
  * counts of the finished rows -- the `bgnn_domain_sums_f64` of the NEXT conv's input for free (heads == 1 only).
+ * tile_queue_opt (8 x uint32 scratch, zeroed here on `stream`) switches the persistent blocks from static tile
+ * striding to per-XCD dynamic tile counters (keeps the rows in flight inside the XCD's L2).
  * D <= 256; ldh % 4 == 0, ldo % 4 == 0, 16-B aligned tables; pad columns must be zero.        */
 int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                    const float* a_t2s, const float* a_s2t,
@@ -110,7 +112,7 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
                                    float* out, int64_t ldo, float* alpha_opt,
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                    float* state_ms_opt, int part, int32_t heads, double* colsum_opt,
-                                   void* stream);
+                                   uint32_t* tile_queue_opt, void* stream);
 
 /*  backward of the aggregation above -- what autograd computes through
  * models/KTGNN.py:292-305 when main_graph_knowledge_transfer.py:39-68 calls loss.backward().
