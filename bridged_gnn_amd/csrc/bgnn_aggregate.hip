@@ -237,6 +237,259 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   }
 }
 
+// ---- wide rows (LF >= 16 lanes per row, i.e. D > 32) ------------------------------------------------------------
+// Same mapping as agg_kernel<LF,1,U>, rebuilt around the VALU budget (the ISA of agg_kernel<32,1,4> spends ~220 VALU
+// issues + ~30 quarter-rate integer multiplies per 4 edges; with the gathers mostly L2 hits that, not HBM, is the bound):
+//  * the U per-edge logit partials are reduced with a TRANSPOSING butterfly: each xor step halves the number of live
+//    values (lane keeps the partial of the edge whose bit matches its lane bit and sends the other), so after log2(U)
+//    steps lane l holds the quad-sum of edge (l & (U-1)) -- U-1 DPP adds instead of U*log2(LF); the remaining
+//    log2(LF/U) steps run on ONE value.  exp() is then evaluated once per lane for "its" edge (2 transcendental
+//    issues per U edges instead of U+1) and the weights return to all lanes as the DPP operand of the FMAs;
+//  * leaky_relu(z) = max(z, slope*z) (0 <= slope <= 1; exact) on packed pairs: v_pk_add / v_pk_mul / v_pk_fma;
+//  * one neighbour id per lane per step (edge l & (U-1)), broadcast by quad_perm, instead of U guarded loads;
+//  * neighbour address = base + id * stride as ONE v_mad_u64_u32; tail edges gather row 0 (valid memory) with
+//    weight 0 instead of branching around the load.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float x) { return bgnn::dpp_mov<K * 0x55>(x); }
+template <int K>
+__device__ __forceinline__ int quad_bcasti(int x) { return dpp_movi<K * 0x55>(x); }
+
+// butterfly step over lane bit `CTRL`: keep the value of my side, add the partner's partial of the same edge
+template <int CTRL>
+__device__ __forceinline__ float bfly(bool hi_side, float t_lo, float t_hi) {
+  const float keep = hi_side ? t_hi : t_lo;
+  const float send = hi_side ? t_lo : t_hi;
+  return keep + bgnn::dpp_mov<CTRL>(send);
+}
+
+template <int LF, int U>
+__global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
+  static_assert(LF == 16 || LF == 32 || LF == 64, "wide rows only");
+  static_assert(U == 4 || U == 8, "U");
+  constexpr int GPW = 64 / LF;           // rows per wave
+  constexpr int RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / LF;
+  const int lg = lane % LF;
+  const int f0 = lg * 4;
+  const bool fvalid = f0 < p.D;
+  const int f0c = fvalid ? f0 : 0;       // pad lanes read column 0 (valid memory); their attention weights are 0
+  const int k = lane & (U - 1);          // the edge slot of a step this lane scores
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+
+  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  __shared__ float red[2][LF * 4 + 1];
+  if (p.colsum != nullptr) {
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) (&red[0][0])[t] = 0.f;
+    __syncthreads();
+  }
+  __shared__ unsigned int dyn_tile;
+  const int64_t xbase = tr.begin - (blockIdx.x / 8);
+  const uint32_t nstride = (uint32_t)(p.heads * p.ldh * 4);   // bytes between neighbour rows of one head (host-checked < 2^32)
+  const f2 sl = {p.slope, p.slope};
+  float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // column sums of the rows this lane wrote, per domain
+  float n_s = 0.f, n_t = 0.f;
+  int64_t tile = tr.begin - tr.step;
+  for (;;) {
+    if (p.tile_queue != nullptr) {
+      __syncthreads();
+      if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
+      __syncthreads();
+      tile = xbase + dyn_tile;
+    } else {
+      tile += tr.step;
+    }
+    if (tile >= tr.end) break;
+    const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.row_end * p.heads;
+    const int64_t ic = rvalid ? i : p.row_begin * p.heads;
+    const int64_t node = ic / p.heads;
+    const int head = (int)(ic - node * p.heads);
+    const bool dom_s = p.mask[node] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = (dom_s ? p.a_t2s : p.a_s2t) + head * p.D;
+    const int32_t beg = rvalid ? p.rowptr[node] : 0;
+    const int32_t end = rvalid ? p.rowptr[node + 1] : 0;
+    const char* __restrict__ Hb = reinterpret_cast<const char*>(H + (int64_t)head * p.ldh + f0c);
+
+    f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    if (fvalid) {
+      a01.x = av[f0];
+      a01.y = f0 + 1 < p.D ? av[f0 + 1] : 0.f;
+      a23.x = f0 + 2 < p.D ? av[f0 + 2] : 0.f;
+      a23.y = f0 + 3 < p.D ? av[f0 + 3] : 0.f;
+    }
+    const float4 hi4 = *reinterpret_cast<const float4*>(H + ic * p.ldh + f0c);
+    const f2 h01 = {hi4.x, hi4.y}, h23 = {hi4.z, hi4.w};
+
+    float m = -INFINITY, s = 0.f;          // s: per-lane partial (sum over the steps of "my" edge slot)
+    f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    if (p.mode == 2 && rvalid) {
+      m = p.state_ms[2 * i];
+      if (k == 0) s = p.state_ms[2 * i + 1];
+      if (f0 < p.ldo) {
+        const float4 t = *reinterpret_cast<const float4*>(p.out + i * p.ldo + f0);
+        acc01 = f2{t.x, t.y}; acc23 = f2{t.z, t.w};
+      }
+    }
+    const int32_t niter = (end - beg + U - 1) / U;
+    // issue the U row gathers of one step from the per-lane ids (lane l holds the id of slot l & (U-1))
+    auto issue = [&](float4 (&v)[U], int32_t myid) {
+      int32_t id[U];
+      if constexpr (U == 4) {
+        id[0] = quad_bcasti<0>(myid); id[1] = quad_bcasti<1>(myid);
+        id[2] = quad_bcasti<2>(myid); id[3] = quad_bcasti<3>(myid);
+      } else {
+        const int32_t oth = dpp_movi<0x124>(myid);          // row_ror:4 -> the other quad of my 8 (an id of slot k^4)
+        const int32_t lo = b2 ? oth : myid, hi = b2 ? myid : oth;
+        id[0] = quad_bcasti<0>(lo); id[1] = quad_bcasti<1>(lo); id[2] = quad_bcasti<2>(lo); id[3] = quad_bcasti<3>(lo);
+        id[4] = quad_bcasti<0>(hi); id[5] = quad_bcasti<1>(hi); id[6] = quad_bcasti<2>(hi); id[7] = quad_bcasti<3>(hi);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t r = (uint32_t)max(id[u], 0);
+        v[u] = *reinterpret_cast<const float4*>(Hb + (uint64_t)r * nstride);
+      }
+    };
+    // score + online-softmax update for one step whose rows are in v (myid: this lane's slot id, e_cur: its edge)
+    auto update = [&](const float4 (&v)[U], int32_t myid, int32_t e_cur) {
+      float t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        f2 z0 = f2{v[u].x, v[u].y} + h01, z1 = f2{v[u].z, v[u].w} + h23;
+        z0 = __builtin_elementwise_max(z0, z0 * sl);
+        z1 = __builtin_elementwise_max(z1, z1 * sl);
+        f2 q = a01 * z0;
+        q = __builtin_elementwise_fma(a23, z1, q);
+        t[u] = q.x + q.y;
+      }
+      float r;
+      if constexpr (U == 4) {
+        const float rA = bfly<0xB1>(b0, t[0], t[1]), rB = bfly<0xB1>(b0, t[2], t[3]);
+        r = bfly<0x4E>(b1, rA, rB);
+        r += bgnn::dpp_mov<0x124>(r);                       // row_ror:4 (keeps lane & 3)
+      } else {
+        const float r0 = bfly<0xB1>(b0, t[0], t[1]), r1 = bfly<0xB1>(b0, t[2], t[3]);
+        const float r2 = bfly<0xB1>(b0, t[4], t[5]), r3 = bfly<0xB1>(b0, t[6], t[7]);
+        const float rA = bfly<0x4E>(b1, r0, r1), rB = bfly<0x4E>(b1, r2, r3);
+        r = bfly<0x124>(b2, rA, rB);                        // rotation by 4: every partial is received exactly once
+      }
+      r += bgnn::dpp_mov<0x128>(r);                         // row_ror:8
+      if constexpr (LF >= 32) r += bgnn::swz_xor16(r);
+      if constexpr (LF >= 64) r += __shfl_xor(r, 32);
+      const float l = myid >= 0 ? r : -INFINITY;
+      if (p.alpha != nullptr && lg < U && myid >= 0) p.alpha[e_cur] = l;     // raw logit, normalised below
+
+      float cm = fmaxf(l, bgnn::dpp_mov<0xB1>(l));
+      cm = fmaxf(cm, bgnn::dpp_mov<0x4E>(cm));
+      if constexpr (U == 8) cm = fmaxf(cm, bgnn::dpp_mov<0x124>(cm));
+      const float mn = fmaxf(m, cm);
+      const float sc = (m == mn) ? 1.f : __expf(m - mn);
+      const float pe = (l == -INFINITY) ? 0.f : __expf(l - mn);
+      s = fmaf(s, sc, pe);
+      const f2 sc2 = {sc, sc};
+      acc01 *= sc2; acc23 *= sc2;
+      float pl = pe, ph = pe;
+      if constexpr (U == 8) {
+        const float oth = bgnn::dpp_mov<0x124>(pe);
+        pl = b2 ? oth : pe; ph = b2 ? pe : oth;
+      }
+#define BGNN_ACC(u, w)                                               \
+      {                                                              \
+        acc01.x = fmaf(w, v[u].x, acc01.x); acc01.y = fmaf(w, v[u].y, acc01.y); \
+        acc23.x = fmaf(w, v[u].z, acc23.x); acc23.y = fmaf(w, v[u].w, acc23.y); \
+      }
+      { const float w = quad_bcast<0>(pl); BGNN_ACC(0, w) }
+      { const float w = quad_bcast<1>(pl); BGNN_ACC(1, w) }
+      { const float w = quad_bcast<2>(pl); BGNN_ACC(2, w) }
+      { const float w = quad_bcast<3>(pl); BGNN_ACC(3, w) }
+      if constexpr (U == 8) {
+        { const float w = quad_bcast<0>(ph); BGNN_ACC(4, w) }
+        { const float w = quad_bcast<1>(ph); BGNN_ACC(5, w) }
+        { const float w = quad_bcast<2>(ph); BGNN_ACC(6, w) }
+        { const float w = quad_bcast<3>(ph); BGNN_ACC(7, w) }
+      }
+#undef BGNN_ACC
+      m = mn;
+    };
+    auto slot_id = [&](int32_t e) { return e < end ? p.col[e] : -1; };
+
+    // (issuing step it+1's gathers before scoring step it -- two steps in flight -- measured no gain on MI355X at
+    //  any of U = 4/8, occupancy 4..6: the gather rate, not the latency per wave, is the bound; profiles/r01/README.md)
+    int32_t e = beg + k;
+    int32_t myid = slot_id(e);
+    for (int32_t it = 0; it < niter; ++it) {
+      float4 v[U];
+      issue(v, myid);
+      const int32_t nextid = slot_id(e + U);
+      update(v, myid, e);
+      e += U;
+      myid = nextid;
+    }
+    // the row's denominator: sum of the U per-slot partials
+    s += bgnn::dpp_mov<0xB1>(s);
+    s += bgnn::dpp_mov<0x4E>(s);
+    if constexpr (U == 8) s += bgnn::dpp_mov<0x124>(s);
+
+    if (p.mode == 1) {
+      if (rvalid) {
+        if (lg == 0) { p.state_ms[2 * i] = m; p.state_ms[2 * i + 1] = s; }
+        if (f0 < p.ldo)
+          *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) =
+              fvalid ? make_float4(acc01.x, acc01.y, acc23.x, acc23.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
+    const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
+    if (p.alpha != nullptr && lg < U) {     // the lane that wrote a raw logit normalises it (program order, no fence)
+      for (int32_t e2 = beg + lg; e2 < end; e2 += U) p.alpha[e2] = __expf(p.alpha[e2] - m) * inv;
+    }
+    if (rvalid && f0 < p.ldo) {
+      float4 o = make_float4(acc01.x * inv, acc01.y * inv, acc23.x * inv, acc23.y * inv);
+      if (p.ep_scale != nullptr) {
+        float sc4[4], sh4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = f0 + c < p.D;
+          sc4[c] = ok ? p.ep_scale[f0 + c] : 0.f;
+          sh4[c] = ok ? p.ep_shift[f0 + c] : 0.f;
+        }
+        o.x = fmaf(o.x, sc4[0], sh4[0]); o.y = fmaf(o.y, sc4[1], sh4[1]);
+        o.z = fmaf(o.z, sc4[2], sh4[2]); o.w = fmaf(o.w, sc4[3], sh4[3]);
+      }
+      if (p.ep_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = o;
+      if (p.colsum != nullptr) {            // per-lane fp32 partials over the <= few hundred rows this lane finishes
+        if (dom_s) { cs_s.x += o.x; cs_s.y += o.y; cs_s.z += o.z; cs_s.w += o.w; n_s += 1.f; }
+        else       { cs_t.x += o.x; cs_t.y += o.y; cs_t.z += o.z; cs_t.w += o.w; n_t += 1.f; }
+      }
+    }
+  }
+  if (p.colsum != nullptr) {
+    // lanes -> LDS (ds_add_f32) -> one hardware fp64 atomic per (block, column, domain)
+    unsafeAtomicAdd(&red[0][f0], cs_s.x); unsafeAtomicAdd(&red[0][f0 + 1], cs_s.y);
+    unsafeAtomicAdd(&red[0][f0 + 2], cs_s.z); unsafeAtomicAdd(&red[0][f0 + 3], cs_s.w);
+    unsafeAtomicAdd(&red[1][f0], cs_t.x); unsafeAtomicAdd(&red[1][f0 + 1], cs_t.y);
+    unsafeAtomicAdd(&red[1][f0 + 2], cs_t.z); unsafeAtomicAdd(&red[1][f0 + 3], cs_t.w);
+    if (lg == 0) { unsafeAtomicAdd(&red[0][LF * 4], n_s); unsafeAtomicAdd(&red[1][LF * 4], n_t); }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) {
+      const int d = t / (LF * 4 + 1), c = t % (LF * 4 + 1);
+      const double sum = (double)red[d][c];
+      if (c == LF * 4) unsafeAtomicAdd(&p.colsum[2 * p.ldo + d], sum);
+      else if (c < p.ldo) unsafeAtomicAdd(&p.colsum[d * p.ldo + c], sum);
+    }
+  }
+}
+
 // Narrow multi-head variant (D <= 4, i.e. one float4 per head): ONE lane group walks a destination's in-edges
 // for all HEADS convs at once -- the neighbour id is read once and the HEADS x 16-B pieces of a neighbour row
 // are independent loads, so the per-edge latency chain is shared instead of repeated per head.
@@ -394,6 +647,25 @@ int launch(const AggParams& p, hipStream_t st) {
   return 0;
 }
 
+template <int LF, int U>
+int launch_wide(const AggParams& p, hipStream_t st) {
+  constexpr int RPB = 4 * (64 / LF);
+  static const int cap = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_kernel<LF, U>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu * prop.multiProcessorCount / 8 * 8;
+  }();
+  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
+  int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
@@ -429,6 +701,13 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if (nv <= 2) return launch<2, 2, 4>(p, st);
   if (nv <= 4) return launch<4, 1, 8>(p, st);
   if (nv <= 8) return launch<8, 1, 4>(p, st);
+  // wide rows: the VALU-lean kernel (needs max(z, slope*z) == leaky_relu and 32-bit row strides)
+  const bool wide_ok = negative_slope >= 0.f && negative_slope <= 1.f && (int64_t)heads * ldh * 4 < (int64_t)1 << 32;
+  if (wide_ok) {
+    if (nv <= 16) return launch_wide<16, 4>(p, st);
+    if (nv <= 32) return launch_wide<32, 4>(p, st);
+    return launch_wide<64, 4>(p, st);
+  }
   if (nv <= 16) return launch<16, 1, 8>(p, st);
   if (nv <= 32) return launch<32, 1, 4>(p, st);
   return launch<64, 1, 4>(p, st);
@@ -441,11 +720,18 @@ extern "C" int bgnn_tune_reset_counters(void* stream) { (void)stream; return 0; 
 extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64_t ldh, const float* a_t2s,
                                    const float* a_s2t, const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
                                    int64_t row_begin, int64_t row_end, int32_t D, float slope, float* out, int64_t ldo,
-                                   int variant, void* stream) {
+                                   int variant, uint32_t* tile_queue, void* stream) {
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
-              out, ldo, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, 0};
+              out, ldo, nullptr, nullptr, nullptr, 0, tile_queue, nullptr, 1, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
+  if (tile_queue && hipMemsetAsync(tile_queue, 0, 32, st) != hipSuccess) return -1;
   switch (variant) {
+    case 40: return launch_wide<32, 4>(p, st);
+    case 41: return launch_wide<32, 8>(p, st);
+    case 42: return launch_wide<16, 4>(p, st);
+    case 43: return launch_wide<16, 8>(p, st);
+    case 44: return launch_wide<64, 4>(p, st);
+    case 45: return launch_wide<64, 8>(p, st);
     // D = 128 (LF = 32)
     case 0: return launch<32, 1, 4>(p, st);
     case 1: return launch<32, 1, 8>(p, st);
@@ -453,6 +739,7 @@ extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64
     case 3: return launch<32, 2, 2>(p, st);
     case 4: return launch<32, 1, 2>(p, st);
     case 5: return launch<32, 2, 8>(p, st);
+    case 6: return launch<64, 1, 4>(p, st);
     // D <= 4 (LF = 1)
     case 10: return launch<1, 8, 2>(p, st);
     case 11: return launch<1, 4, 4>(p, st);

@@ -13,19 +13,22 @@
 // is applied in the epilogue.  x is read from HBM once, the [N,Din] shifted copies and the gate
 // vector the reference materialises never exist.  The contraction is the only MFMA work on path B:
 // v_mfma_f32_32x32x2_f32, exact-fp32 fmaf chains.
+#include <cstdlib>
 #include "bgnn_common.h"
 
 namespace {
 
 // ------------------------------------------------------------------ per-domain column sums (fp64)
 // thread = (column float4 lane, row lane); 4 rows in flight per thread; block partials via LDS, one
-// fp64 atomic per (block, column, domain).
-__global__ __launch_bounds__(256) void domain_sums_kernel(const float* __restrict__ x, int64_t N, int32_t Din,
+// fp64 atomic per (block, column, domain).  Device-scope fp64 atomics on the same 2*Din addresses retire at only
+// ~3 G/s (measured: +90 ns per block), so the launch is ONE 1024-thread block per CU rather than many small ones.
+constexpr int DS_NT = 1024;
+__global__ __launch_bounds__(DS_NT) void domain_sums_kernel(const float* __restrict__ x, int64_t N, int32_t Din,
                                                           int64_t ldx, const uint8_t* __restrict__ mask,
                                                           double* __restrict__ sums) {
   const int nc4 = Din >> 2;                       // Din % 4 == 0
   const int cw = nc4 < 256 ? nc4 : 256;           // column lanes
-  const int rl = 256 / cw;                        // row lanes
+  const int rl = DS_NT / cw;                       // row lanes
   const int tid = threadIdx.x;
   const int cl = tid % cw, r0 = tid / cw;
   const bool active = r0 < rl;
@@ -75,12 +78,17 @@ __global__ __launch_bounds__(256) void domain_sums_kernel(const float* __restric
     __syncthreads();
   }
   float cs = 0.f, ct = 0.f;                         // node counts (exact in fp32 up to 2^24 per thread)
-  for (int64_t r = rb + tid; r < re; r += 256) { if (mask[r]) cs += 1.f; else ct += 1.f; }
+  for (int64_t r = rb + tid; r < re; r += DS_NT) { if (mask[r]) cs += 1.f; else ct += 1.f; }
   cs = bgnn::group_sum<64>(cs);
   ct = bgnn::group_sum<64>(ct);
-  if ((tid & 63) == 0) {
-    unsafeAtomicAdd(&sums[2 * Din], (double)cs);
-    unsafeAtomicAdd(&sums[2 * Din + 1], (double)ct);
+  // one pair of atomics per BLOCK: atomics on one address serialise at the memory side (~20 ns each), and
+  // 4096 waves x 2 of them used to cost more than streaming x
+  if ((tid & 63) == 0) { sh[2 * (tid >> 6)] = (double)cs; sh[2 * (tid >> 6) + 1] = (double)ct; }
+  __syncthreads();
+  if (tid < 2) {
+    double t = 0.0;
+    for (int w = 0; w < DS_NT / 64; ++w) t += sh[2 * w + tid];
+    unsafeAtomicAdd(&sums[2 * Din + tid], t);
   }
 }
 
@@ -315,10 +323,11 @@ extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int6
   if (N < 0 || Din <= 0 || ldx < Din || (Din & 3) || (ldx & 3)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
-  const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = 256 / cw;
-  int64_t grid = (N + 63) / 64;
-  if (grid > 1024) grid = 1024;      // few, long-running blocks: 1024 x 2*Din fp64 atomics in total
-  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(256), sizeof(double) * rl * 2 * cw * 4,
+  const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = DS_NT / cw;
+  int64_t grid = (N + 255) / 256;
+  static const int64_t gcap = [] { const char* e = getenv("BGNN_DS_GRID"); return e ? atoll(e) : 256ll; }();
+  if (grid > gcap) grid = gcap;
+  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(DS_NT), sizeof(double) * rl * 2 * cw * 4,
                      (hipStream_t)stream, x, N, Din, ldx, mask, sums_io);
   BGNN_LAUNCH_CHECK();
   return 0;

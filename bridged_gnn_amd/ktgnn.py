@@ -192,7 +192,8 @@ class AdaptedConv(nn.Module):
         return csr
 
     def forward(self, x, edge_index, edge_index1=None, edge_index2=None, central_mask=None, size=None,
-                csr=None, delta=None, epilogue=None, return_alpha=False, colsum=None):
+                csr=None, delta=None, epilogue=None, return_alpha=False, colsum=None, sums=None):
+        """`sums`: per-domain column sums of x if the producer already has them (the previous conv's `colsum`)."""
         if isinstance(x, (tuple, list)):
             x_src, x_r = x
         else:
@@ -217,7 +218,7 @@ class AdaptedConv(nn.Module):
                 out = out * sc + sh
                 out = F.relu(out) if relu else out
             return out
-        h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta)
+        h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta, sums=sums)
         fuse = epilogue if not (self.root_weight or self.normalize) else None
         if colsum is not None and (fuse is None and epilogue is not None or self.root_weight or self.normalize):
             raise ValueError("colsum needs the fused epilogue path")
@@ -300,20 +301,21 @@ class KTGNN_no_complement(nn.Module):
         return csr
 
     def _hidden(self, x, csr, central_mask, want_sums=False):
-        """hidden stack (KTGNN.py:418-430).  With `want_sums` the last conv's epilogue also accumulates the
-        per-domain column sums of its output (= the classifier convs' domain sums) when the fused path is taken."""
+        """hidden stack (KTGNN.py:418-430).  On the fused eval path every conv's aggregation epilogue also accumulates
+        the per-domain column sums of its output, i.e. the domain sums (KTGNN.py:275) of the NEXT conv's input, so
+        only the first conv streams its input an extra time; `want_sums` returns the last conv's."""
         sums = None
         for ind, conv in enumerate(self.convs):                                   # :418-430
-            last = ind == len(self.convs) - 1
+            sums_in, sums = sums, None
             if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters())):
                 bn = self.bns[ind]
                 sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
                 sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
-                if want_sums and last and not (conv.root_weight or conv.normalize):
+                if not (conv.root_weight or conv.normalize):
                     sums = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=x.device)
-                x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums)
+                x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
             else:
-                x = conv(x, None, central_mask=central_mask, csr=csr)
+                x = conv(x, None, central_mask=central_mask, csr=csr, sums=sums_in)
                 if self.use_bn:
                     x = self.bns[ind](x)
                 x = F.relu(x)
@@ -367,9 +369,7 @@ class KTGNN_no_complement(nn.Module):
     def forward(self, data):
         x, central_mask = data.x, data.central_mask
         csr = self._prepare(data)
-        # (the aggregation epilogue can also collect the next conv's domain sums -- `colsum`; measured neutral on MI355X:
-        #  +0.19 ms in the HBM-bound kernel vs 0.19 ms for the separate streaming pass -- so it stays off here)
-        x, sums_h = self._hidden(x, csr, central_mask, want_sums=False), None
+        x, sums_h = self._hidden(x, csr, central_mask, want_sums=True)
         x = x.contiguous()
         mask_u8 = _as_u8(central_mask).contiguous()
         if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:

@@ -16,7 +16,7 @@ from bridged_gnn_amd import ops, synth  # noqa: E402
 lib = C.CDLL(os.path.join(ROOT, "tools", os.environ.get("TUNE_LIB", "libbgnn_tune.so")))
 P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 lib.bgnn_tune_aggregate.restype = C.c_int
-lib.bgnn_tune_aggregate.argtypes = [P, P, I64, P, P, P, P, P, I64, I64, I32, F32, P, I64, C.c_int, P]
+lib.bgnn_tune_aggregate.argtypes = [P, P, I64, P, P, P, P, P, I64, I64, I32, F32, P, I64, C.c_int, P, P]
 dev = "cuda:0"
 
 
@@ -33,11 +33,13 @@ def run(graph, D, variants, n=1_000_000):
     ref = None
     res = {}
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    queue = torch.zeros(8, dtype=torch.int32, device=dev)
+    qp = queue.data_ptr() if os.environ.get('TUNE_QUEUE', '1') == '1' else None
     for v in variants:
         def call():
             lib.bgnn_tune_reset_counters(None)
             rc = lib.bgnn_tune_aggregate(hS.data_ptr(), hT.data_ptr(), ld, a1.data_ptr(), a2.data_ptr(), csr.rowptr.data_ptr(),
-                                         csr.col.data_ptr(), m8.data_ptr(), 0, n, D, 0.1, out.data_ptr(), ld, v, st)
+                                         csr.col.data_ptr(), m8.data_ptr(), 0, n, D, 0.1, out.data_ptr(), ld, v, qp, st)
             assert rc == 0, rc
         for _ in range(3):
             call()
@@ -58,8 +60,11 @@ def run(graph, D, variants, n=1_000_000):
 if __name__ == "__main__":
     allres = {}
     if os.environ.get("TUNE_QUICK"):
-        allres["local_D128"] = run("local", 128, [0, 4])
-        allres["uniform_D128"] = run("uniform", 128, [0])
+        allres["local_D128"] = run("local", 128, [0, 40, 41])
+        allres["uniform_D128"] = run("uniform", 128, [0, 40, 41])
+        allres["local_D64"] = run("local", 64, [23, 42, 43])
+        allres["local_D100"] = run("local", 100, [0, 40, 41])
+        allres["local_D256"] = run("local", 256, [6, 44, 45], n=500_000)
     else:
         for graph in ("local", "uniform"):
             allres[f"{graph}_D128"] = run(graph, 128, [0, 1, 2, 3, 4, 5])
