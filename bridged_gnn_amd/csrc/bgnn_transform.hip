@@ -14,6 +14,7 @@
 // vector the reference materialises never exist.  The contraction is the only MFMA work on path B:
 // v_mfma_f32_32x32x2_f32, exact-fp32 fmaf chains.
 #include <cstdlib>
+#include <type_traits>
 #include "bgnn_common.h"
 
 namespace {
@@ -315,6 +316,237 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------ W-stationary variant (NC > 32, Din <= 128)
+// transform_gemm_kernel re-stages the [BN, 32] slab of W into LDS for every 128-row tile and pays a block-wide
+// prologue / epilogue per tile; measured 0.87 ms on the [1M,128]x[128,256] hidden transform, of which 0.42 ms is fp32
+// MFMA issue.  Here the weights never move: wave w keeps "its" 32 output columns of W in registers for the whole
+// kernel (the MFMA A operand: Din/2 VGPRs), the block is persistent (one per CU) and walks 32-row tiles of x that are
+// double-buffered in LDS (the B operand, shared by the 8 waves) -- one barrier per tile, the next tile's global loads
+// fly during the MFMA phase, and with x as the B operand a lane ends up holding 4 CONSECUTIVE output columns of one row,
+// so results leave as 16-byte stores straight from the accumulators (no C staging pass).
+//   DK  : Din rounded up to 64/128 (zero-filled),  NCT : 32-column tiles per block (2/4/8); 8/NCT row sub-tiles.
+// tanh through v_exp_f32 + v_rcp_f32 (abs. error < 5e-7; the coefficient scales an O(1) rank-1 term)
+__device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f); }
+
+template <int DK, int NCT, int NW>
+__global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
+  constexpr int RS = NW / NCT;               // row sub-tiles (LDS: 2 x 32*RS x (DK+4) floats)
+  constexpr int RPP = 4 * NW;                // staging: rows per pass (16 lanes per row)
+  constexpr int BMW = 32 * RS, LD = DK + 4;
+  constexpr int KB = DK / 8;                 // 16-byte k chunks per lane half
+  constexpr int CPT = DK / 64;               // staging: 16 lanes cover a row, CPT float4 each (256-B runs)
+  constexpr int NP = BMW / RPP;              // staging passes
+  static_assert(NW % NCT == 0 && BMW % RPP == 0, "wave layout");
+  constexpr int PRE_LD = MAXH * 2 + 1;       // gate pre-activations of a row + its domain flag
+  __shared__ __attribute__((aligned(16))) float xs[2][BMW * LD];
+  __shared__ float pre[2][BMW][PRE_LD];
+  constexpr int CT_LD = 36;                  // wave-private 32x32 output tile (+4 floats: conflict-free b128 writes)
+  __shared__ __attribute__((aligned(16))) float ctile[NW][32 * CT_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, clean waitcnt placement
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ct = wave % NCT, rs = wave / NCT;
+  const int col_base = blockIdx.y * (32 * NCT) + ct * 32;
+  // (host guarantees NC % (32 * NCT) == 0: every wave owns a full column tile -- no per-wave branches in the tile loop,
+  //  which keeps the compiler's s_waitcnt placement exact)
+
+  // ---- stationary operands -------------------------------------------------------------------------------
+  float wreg[KB * 4];                         // W[col_base + fr][8kb + 4fh + j]  (the same k permutation as the x reads)
+  {
+    const int n = col_base + fr;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int k = 8 * kb + 4 * fh;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.NC && k < p.Din) w = *reinterpret_cast<const float4*>(p.Wp + (int64_t)n * p.Din + k);
+      wreg[4 * kb] = w.x; wreg[4 * kb + 1] = w.y; wreg[4 * kb + 2] = w.z; wreg[4 * kb + 3] = w.w;
+    }
+  }
+  // epilogue constants: accumulator registers 4q..4q+3 of a lane are columns col_base + 8q + 4fh + (0..3) of row fr
+  float4 bv[4], wv[4];
+  int hsel[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = col_base + 8 * q + 4 * fh;
+    bv[q] = wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    hsel[q] = 0;
+    if (c < p.NC) {
+      const int ld2 = 2 * (int)p.ldh;
+      const int h = c / ld2, rem = c % ld2, t = rem >= p.ldh ? 1 : 0;
+      bv[q] = *reinterpret_cast<const float4*>(p.bias + c);
+      wv[q] = *reinterpret_cast<const float4*>(p.wd + c);
+      hsel[q] = h * 2 + t;
+    }
+  }
+  // store side (after the transpose): lane owns columns col_base + 4*(lane & 7) .. +3 of rows (lane >> 3) + 8i
+  float* ocol = nullptr;
+  {
+    const int c = col_base + 4 * (lane & 7);
+    if (c < p.NC) {
+      const int ld2 = 2 * (int)p.ldh;
+      const int h = c / ld2, rem = c % ld2, t = rem >= p.ldh ? 1 : 0;
+      float* base = h == 0 ? (t == 0 ? p.out[0][0] : p.out[0][1]) : (t == 0 ? p.out[1][0] : p.out[1][1]);
+      ocol = base + (rem - t * (int)p.ldh);
+    }
+  }
+  // staging: 16 consecutive lanes own one row; lane l16 holds float4 chunks l16 + 16c (c < CPT) -> its gate slices are fixed
+  const int l16 = tid & 15, srow = tid >> 4;
+  float4 g4[MAXH][2][CPT];
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int k = (l16 + 16 * c) * 4;
+        g4[h][t][c] = (k < p.Din && h < p.n_heads) ? *reinterpret_cast<const float4*>(p.g + ((int64_t)(h * 2 + t) * 2) * p.Din + k)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  float gcs[MAXH * 2];
+#pragma unroll
+  for (int h = 0; h < MAXH * 2; ++h) gcs[h] = h < 2 * p.n_heads ? p.gc[h] : 0.f;
+
+  float4 ra[NP][CPT];
+  uint8_t rm[NP];
+  // branch-free loads (tail rows re-read row N-1, chunks past Din re-read chunk 0 and are zeroed): with every load
+  // and its count unconditional the compiler can place exact s_waitcnt vmcnt(n) instead of draining the queue
+  auto gload = [&](int64_t tl) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      int64_t r = tl * BMW + srow + RPP * j;
+      r = r < p.N ? r : p.N - 1;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int k = (l16 + 16 * c) * 4;
+        const bool kv = k < p.Din;
+        float4 v = *reinterpret_cast<const float4*>(p.x + r * p.ldx + (kv ? k : 0));
+        if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[j][c] = v;
+      }
+      rm[j] = p.mask[r];
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int lr = srow + RPP * j;
+      float d[MAXH * 2];
+#pragma unroll
+      for (int h = 0; h < MAXH * 2; ++h) d[h] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const float4 v = ra[j][c];
+        *reinterpret_cast<float4*>(&xs[buf][lr * LD + (l16 + 16 * c) * 4]) = v;
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            float a = d[h * 2 + t];
+            a = fmaf(v.x, g4[h][t][c].x, a); a = fmaf(v.y, g4[h][t][c].y, a);
+            a = fmaf(v.z, g4[h][t][c].z, a); a = fmaf(v.w, g4[h][t][c].w, a);
+            d[h * 2 + t] = a;
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < MAXH * 2; ++h) d[h] = bgnn::group_sum<16>(d[h]) + gcs[h];
+      // lanes 0..4 of the 16 publish the row's four pre-activations and its domain flag (tanh is taken by the consumer)
+      float val = rm[j] != 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int h = 0; h < MAXH * 2; ++h) val = l16 == h ? d[h] : val;
+      if (l16 < PRE_LD) pre[buf][lr][l16] = val;
+    }
+  };
+
+  const int64_t ntiles = (p.N + BMW - 1) / BMW, last = ntiles - 1;     // gridDim.x <= ntiles (host)
+  int64_t tile = blockIdx.x;
+  gload(tile);
+  sstore(0);
+  gload(min(tile + (int64_t)gridDim.x, last));
+  __builtin_amdgcn_s_waitcnt(0x0F70);         // enter the loop with no load pending (see the comment before the epilogue)
+#if defined(GEMM_EXP) && GEMM_EXP == 15
+  if (blockIdx.y & 1) __builtin_amdgcn_s_sleep(60);
+#endif
+  // Two copies of the tile loop (early / late staging), selected per wave: same barrier count on both paths.
+  auto tile_loop = [&](auto late_tag) {
+  constexpr bool LATE = decltype(late_tag)::value;
+  for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {   // block-uniform trip count
+    const int cur = it & 1;
+    __syncthreads();                          // buffer `cur` is complete; nobody still reads buffer cur^1
+    // tile it+1 goes registers -> LDS, tile it+2 starts flying; past the end the last tile is staged again (never read)
+    // The two waves that share a SIMD (w, w + NW/2) stage at opposite ends of the iteration: the early wave's staging
+    // VALU work runs under its partner's MFMAs and vice versa, instead of all waves staging, then all multiplying.
+#if !defined(GEMM_EXP) || (GEMM_EXP != 13 && GEMM_EXP != 14)
+    if constexpr (!LATE) {
+      sstore(cur ^ 1);                                          // tile it+1: registers -> LDS
+      gload(min(tile + 2 * (int64_t)gridDim.x, last));          // tile it+2 flies during the MFMA phase
+    } else {
+      gload(min(tile + (int64_t)gridDim.x, last));              // tile it+1 flies during the MFMA phase, staged below
+    }
+    __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMA chain (the scheduler sinks them to their use)
+#endif
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+    const float* xb = &xs[cur][(rs * 32 + fr) * LD + 4 * fh];
+#if defined(GEMM_EXP) && GEMM_EXP == 11
+    if (p.N < 0)
+#endif
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const float4 b = *reinterpret_cast<const float4*>(xb + 8 * kb);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb], b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 1], b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 2], b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 3], b.w, acc, 0, 0, 0);
+    }
+    }
+    // The loads issued above landed during the MFMA phase; retiring them HERE (vmcnt(0), free) lets the next
+    // iteration's staging start without waiting for the stores below (vmcnt counts loads and stores in order).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+    // epilogue: bias + rank-1 shift in the accumulator layout (lane = row, 4 consecutive columns per q) ...
+    const float* pr = pre[cur][rs * 32 + fr];
+    const bool sdom = pr[MAXH * 2] != 0.f;
+    float* cw = ctile[wave];
+    float cf = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // rank-1 coefficient (KTGNN.py:277-280): -gate_s2t on source rows (table 0), +gate_t2s on target rows (table 1)
+      if (q == 0 || hsel[q] != hsel[q - 1]) {
+        const bool t1 = hsel[q] & 1;
+        cf = (sdom != t1) ? tanh_fast(pr[hsel[q]]) : 0.f;
+        cf = t1 ? cf : -cf;
+      }
+      float4 o;
+      o.x = fmaf(cf, wv[q].x, acc[4 * q] + bv[q].x);     o.y = fmaf(cf, wv[q].y, acc[4 * q + 1] + bv[q].y);
+      o.z = fmaf(cf, wv[q].z, acc[4 * q + 2] + bv[q].z); o.w = fmaf(cf, wv[q].w, acc[4 * q + 3] + bv[q].w);
+      *reinterpret_cast<float4*>(&cw[fr * CT_LD + 8 * q + 4 * fh]) = o;
+    }
+    // ... then a wave-private LDS transpose so every store instruction writes 8 rows x 128 contiguous bytes (whole
+    // cache lines); lane-per-row 16-byte stores scatter one instruction over 32 lines and cost 0.14 ms here
+    if (ocol != nullptr) {
+      const int64_t row0 = tile * BMW + rs * 32 + (lane >> 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&cw[((lane >> 3) + 8 * i) * CT_LD + (lane & 7) * 4]);
+        const int64_t row = row0 + 8 * i;
+#if defined(GEMM_EXP) && (GEMM_EXP == 12 || GEMM_EXP == 14)
+        if (v.x == 12345.678f)
+#endif
+        if (row < p.N) *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
+      }
+    }
+    }
+#if !defined(GEMM_EXP) || (GEMM_EXP != 13 && GEMM_EXP != 14)
+    if constexpr (LATE) sstore(cur ^ 1);
+#endif
+  }
+  };
+  if (wave >= NW / 2) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
+}
+
 }  // namespace
 
 extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
@@ -366,7 +598,27 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
   p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads;
   const int64_t nrt = (N + BM - 1) / BM;
   const int64_t nrt8 = (nrt + 7) / 8 * 8;        // row tiles rounded up to the XCD group size
-  if (NC <= 32) {
+  static const int n_cu = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }();
+  static const bool use_wreg = [] { const char* e = getenv("BGNN_GEMM_WREG"); return !e || atoi(e) != 0; }();
+  if (use_wreg && NC % 64 == 0 && Din <= 128) {   // (Din = 256 needs 128 weight registers per lane and spills)
+    // W-stationary persistent kernel: one 512-thread block per CU, column groups of 32*NCT in grid.y
+    // NC <= 64: 4-wave blocks (2 column tiles x 2 row sub-tiles), two per CU; wider: 8-wave blocks, one per CU
+    const int nct = NC % 256 == 0 ? 8 : NC % 128 == 0 ? 4 : 2;   // full column groups only
+    const int nw = nct == 2 ? 4 : 8;
+    const int bmw = 32 * (nw / nct);
+    const int64_t ntiles = (N + bmw - 1) / bmw;
+    const int ncg = (NC + 32 * nct - 1) / (32 * nct);
+    const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
+    const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), (unsigned)ncg);
+#define BGNN_WREG(DK, NCT, NW) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW>), grid, dim3(64 * NW), 0, st, p)
+#define BGNN_WREG_DK(NCT, NW) do { if (Din <= 64) BGNN_WREG(64, NCT, NW); else BGNN_WREG(128, NCT, NW); } while (0)
+    if (nct == 2) BGNN_WREG_DK(2, 4); else if (nct == 4) BGNN_WREG_DK(4, 8); else BGNN_WREG_DK(8, 8);
+#undef BGNN_WREG_DK
+#undef BGNN_WREG
+  } else if (NC <= 32) {
     hipLaunchKernelGGL((transform_gemm_kernel<32, 4, 1, 1, 1>), dim3((unsigned)nrt8), dim3(256), 0, st, p);
   } else if (NC <= 64) {
     hipLaunchKernelGGL((transform_gemm_kernel<64, 2, 2, 2, 1>), dim3((unsigned)nrt8), dim3(256), 0, st, p);

@@ -24,6 +24,7 @@ Wp, bp, gates, D_, ldh, gconst = ops.pack_transform_heads(heads, Din)
 o1, o2 = torch.empty(N, ldh, device=dev), torch.empty(N, ldh, device=dev)
 small = torch.empty(1024, device=dev)
 for exp in [int(a) for a in sys.argv[1:]] or [0, 1]:
+    print("NW", os.environ.get("BGNN_GEMM_NW"), end=" ")
     lib = C.CDLL(build(exp))
     fn = lib.bgnn_adaptedconv_transform_f32
     fn.restype, fn.argtypes = _lib.SIGNATURES["bgnn_adaptedconv_transform_f32"]
