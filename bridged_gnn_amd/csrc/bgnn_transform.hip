@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, i
 
 // ------------------------------------------------------------------ fused MFMA fp32 GEMM
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BK = 32, LDS_LD = BK + 4;   // +4 floats: conflict-free ds_read_b128 (16-lane groups)
 constexpr int MAXH = 2;
 
@@ -134,6 +136,8 @@ struct GemmParams {
   const float* gc;      // [n_heads][2]         delta-half constants
   float* out[MAXH][2];  // [head][table]  table 0 = h_s2t (W_t), 1 = h_t2s (W_s)
   int64_t ldh; int64_t row_stride; int32_t NC; int32_t n_heads;   // ldh = padded width of a head's row, row_stride >= ldh
+  int32_t relu;         // plain-linear mode (transform_wreg_kernel<.., MODE = 1>): out = relu?(x W^T + b)
+  double* colsum;       // plain-linear mode, optional [2*NC + 2]: per-domain column sums (+ node counts) of the output
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
 // tanh through v_exp_f32 + v_rcp_f32 (abs. error < 5e-7; the coefficient scales an O(1) rank-1 term)
 __device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f); }
 
-template <int DK, int NCT, int NW>
+template <int DK, int NCT, int NW, bool BF3, int MODE>
 __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   constexpr int RS = NW / NCT;               // row sub-tiles (LDS: 2 x 32*RS x (DK+4) floats)
   constexpr int RPP = 4 * NW;                // staging: rows per pass (16 lanes per row)
@@ -339,7 +343,12 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   constexpr int NP = BMW / RPP;              // staging passes
   static_assert(NW % NCT == 0 && BMW % RPP == 0, "wave layout");
   constexpr int PRE_LD = MAXH * 2 + 1;       // gate pre-activations of a row + its domain flag
-  __shared__ __attribute__((aligned(16))) float xs[2][BMW * LD];
+  // BF3: every fp32 value travels as three bf16 pieces (hi + mid + lo = the 24-bit significand) and a product is the six
+  // bf16 MFMAs whose pieces are >= 2^-24 relative; fp32 MFMA shares the VALU datapath on CDNA (same 157 TFLOP/s peak,
+  // VALU work ADDS to it -- measured), the bf16 matrix cores are 16x faster and run beside the VALU.
+  constexpr int LDB = DK + 8;                // bf16 elements per piece row (272-B rows: conflict-free b128 reads)
+  constexpr int XS_FLOATS = BF3 ? (3 * BMW * LDB) / 2 : BMW * LD;
+  __shared__ __attribute__((aligned(16))) float xs[2][XS_FLOATS];
   __shared__ float pre[2][BMW][PRE_LD];
   constexpr int CT_LD = 36;                  // wave-private 32x32 output tile (+4 floats: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float ctile[NW][32 * CT_LD];
@@ -352,15 +361,38 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   //  which keeps the compiler's s_waitcnt placement exact)
 
   // ---- stationary operands -------------------------------------------------------------------------------
-  float wreg[KB * 4];                         // W[col_base + fr][8kb + 4fh + j]  (the same k permutation as the x reads)
+  constexpr int KB16 = DK / 16;               // BF3: 16-wide k blocks; lane half fh holds k = 16kb + 8fh .. +7
+  float wreg[BF3 ? 1 : KB * 4];               // fp32: W[col_base + fr][8kb + 4fh + j]  (the same k permutation as the x reads)
+  bf16x8 wpc[BF3 ? 3 : 1][BF3 ? KB16 : 1];    // BF3: [piece][kb]
   {
     const int n = col_base + fr;
+    if constexpr (!BF3) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const int k = 8 * kb + 4 * fh;
-      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.NC && k < p.Din) w = *reinterpret_cast<const float4*>(p.Wp + (int64_t)n * p.Din + k);
-      wreg[4 * kb] = w.x; wreg[4 * kb + 1] = w.y; wreg[4 * kb + 2] = w.z; wreg[4 * kb + 3] = w.w;
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 8 * kb + 4 * fh;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.NC && k < p.Din) w = *reinterpret_cast<const float4*>(p.Wp + (int64_t)n * p.Din + k);
+        wreg[4 * kb] = w.x; wreg[4 * kb + 1] = w.y; wreg[4 * kb + 2] = w.z; wreg[4 * kb + 3] = w.w;
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < KB16; ++kb) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int k = 16 * kb + 8 * fh + 4 * hf;
+          float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n < p.NC && k < p.Din) w = *reinterpret_cast<const float4*>(p.Wp + (int64_t)n * p.Din + k);
+          const float wf[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)wf[e];
+            const float r1 = wf[e] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 l = (__bf16)(r1 - (float)m);
+            wpc[0][kb][4 * hf + e] = h; wpc[1][kb][4 * hf + e] = m; wpc[2][kb][4 * hf + e] = l;
+          }
+        }
+      }
     }
   }
   // epilogue constants: accumulator registers 4q..4q+3 of a lane are columns col_base + 8q + 4fh + (0..3) of row fr
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       const int ld2 = 2 * (int)p.ldh;
       const int h = c / ld2, rem = c % ld2, t = rem >= p.ldh ? 1 : 0;
       bv[q] = *reinterpret_cast<const float4*>(p.bias + c);
-      wv[q] = *reinterpret_cast<const float4*>(p.wd + c);
+      if constexpr (MODE == 0) wv[q] = *reinterpret_cast<const float4*>(p.wd + c);
       hsel[q] = h * 2 + t;
     }
   }
@@ -400,12 +432,13 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
         const int k = (l16 + 16 * c) * 4;
-        g4[h][t][c] = (k < p.Din && h < p.n_heads) ? *reinterpret_cast<const float4*>(p.g + ((int64_t)(h * 2 + t) * 2) * p.Din + k)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        g4[h][t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (MODE == 0)
+          if (k < p.Din && h < p.n_heads) g4[h][t][c] = *reinterpret_cast<const float4*>(p.g + ((int64_t)(h * 2 + t) * 2) * p.Din + k);
       }
   float gcs[MAXH * 2];
 #pragma unroll
-  for (int h = 0; h < MAXH * 2; ++h) gcs[h] = h < 2 * p.n_heads ? p.gc[h] : 0.f;
+  for (int h = 0; h < MAXH * 2; ++h) gcs[h] = (MODE == 0 && h < 2 * p.n_heads) ? p.gc[h] : 0.f;
 
   float4 ra[NP][CPT];
   uint8_t rm[NP];
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
         if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
         ra[j][c] = v;
       }
-      rm[j] = p.mask[r];
+      rm[j] = (MODE == 0 || p.mask != nullptr) ? p.mask[r] : (uint8_t)0;
     }
   };
   auto sstore = [&](int buf) {
@@ -437,19 +470,41 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
         const float4 v = ra[j][c];
-        *reinterpret_cast<float4*>(&xs[buf][lr * LD + (l16 + 16 * c) * 4]) = v;
+        if constexpr (!BF3) {
+          *reinterpret_cast<float4*>(&xs[buf][lr * LD + (l16 + 16 * c) * 4]) = v;
+        } else {
+          // split 4 floats into (hi, mid, lo) bf16 quadruples: v_cvt_pk_bf16_f32 + exact fp32 residuals
+          const float vf[4] = {v.x, v.y, v.z, v.w};
+          bf16x4 ph, pm, pl;
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            float a = d[h * 2 + t];
-            a = fmaf(v.x, g4[h][t][c].x, a); a = fmaf(v.y, g4[h][t][c].y, a);
-            a = fmaf(v.z, g4[h][t][c].z, a); a = fmaf(v.w, g4[h][t][c].w, a);
-            d[h * 2 + t] = a;
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)vf[e];
+            const float r1 = vf[e] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            ph[e] = h; pm[e] = m; pl[e] = (__bf16)(r1 - (float)m);
           }
-      }
+          __bf16* xb16 = reinterpret_cast<__bf16*>(xs[buf]);
+          const int k = (l16 + 16 * c) * 4;
+          *reinterpret_cast<bf16x4*>(&xb16[(0 * BMW + lr) * LDB + k]) = ph;
+          *reinterpret_cast<bf16x4*>(&xb16[(1 * BMW + lr) * LDB + k]) = pm;
+          *reinterpret_cast<bf16x4*>(&xb16[(2 * BMW + lr) * LDB + k]) = pl;
+        }
+        if constexpr (MODE == 0) {
 #pragma unroll
-      for (int h = 0; h < MAXH * 2; ++h) d[h] = bgnn::group_sum<16>(d[h]) + gcs[h];
+          for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              float a = d[h * 2 + t];
+              a = fmaf(v.x, g4[h][t][c].x, a); a = fmaf(v.y, g4[h][t][c].y, a);
+              a = fmaf(v.z, g4[h][t][c].z, a); a = fmaf(v.w, g4[h][t][c].w, a);
+              d[h * 2 + t] = a;
+            }
+        }
+      }
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int h = 0; h < MAXH * 2; ++h) d[h] = bgnn::group_sum<16>(d[h]) + gcs[h];
+      }
       // lanes 0..4 of the 16 publish the row's four pre-activations and its domain flag (tanh is taken by the consumer)
       float val = rm[j] != 0 ? 1.f : 0.f;
 #pragma unroll
@@ -458,37 +513,29 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
     }
   };
 
+  float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // MODE 1: column sums of the rows this lane stored
+  float n_s = 0.f, n_t = 0.f;
   const int64_t ntiles = (p.N + BMW - 1) / BMW, last = ntiles - 1;     // gridDim.x <= ntiles (host)
   int64_t tile = blockIdx.x;
   gload(tile);
   sstore(0);
   gload(min(tile + (int64_t)gridDim.x, last));
   __builtin_amdgcn_s_waitcnt(0x0F70);         // enter the loop with no load pending (see the comment before the epilogue)
-#if defined(GEMM_EXP) && GEMM_EXP == 15
-  if (blockIdx.y & 1) __builtin_amdgcn_s_sleep(60);
-#endif
-  // Two copies of the tile loop (early / late staging), selected per wave: same barrier count on both paths.
-  auto tile_loop = [&](auto late_tag) {
-  constexpr bool LATE = decltype(late_tag)::value;
   for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {   // block-uniform trip count
     const int cur = it & 1;
     __syncthreads();                          // buffer `cur` is complete; nobody still reads buffer cur^1
     // tile it+1 goes registers -> LDS, tile it+2 starts flying; past the end the last tile is staged again (never read)
-    // The two waves that share a SIMD (w, w + NW/2) stage at opposite ends of the iteration: the early wave's staging
-    // VALU work runs under its partner's MFMAs and vice versa, instead of all waves staging, then all multiplying.
+    // (staggering the staging of the two waves that share a SIMD, or two 4-wave blocks per CU, measured no gain)
 #if !defined(GEMM_EXP) || (GEMM_EXP != 13 && GEMM_EXP != 14)
-    if constexpr (!LATE) {
-      sstore(cur ^ 1);                                          // tile it+1: registers -> LDS
-      gload(min(tile + 2 * (int64_t)gridDim.x, last));          // tile it+2 flies during the MFMA phase
-    } else {
-      gload(min(tile + (int64_t)gridDim.x, last));              // tile it+1 flies during the MFMA phase, staged below
-    }
-    __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMA chain (the scheduler sinks them to their use)
+    sstore(cur ^ 1);                                          // tile it+1: registers -> LDS
+    gload(min(tile + 2 * (int64_t)gridDim.x, last));          // tile it+2 flies during the MFMA phase
 #endif
+    __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMA chain (the scheduler sinks them to their use)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     {
+    if constexpr (!BF3) {
     const float* xb = &xs[cur][(rs * 32 + fr) * LD + 4 * fh];
 #if defined(GEMM_EXP) && GEMM_EXP == 11
     if (p.N < 0)
@@ -500,6 +547,22 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 1], b.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 2], b.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 3], b.w, acc, 0, 0, 0);
+    }
+    } else {
+    const __bf16* xb16 = reinterpret_cast<const __bf16*>(xs[cur]) + (rs * 32 + fr) * LDB + 8 * fh;
+#pragma unroll
+    for (int kb = 0; kb < KB16; ++kb) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xb16 + 0 * BMW * LDB + 16 * kb);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(xb16 + 1 * BMW * LDB + 16 * kb);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xb16 + 2 * BMW * LDB + 16 * kb);
+      // smallest terms first; dropped: mid*lo, lo*mid, lo*lo (< 2^-24 relative)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[2][kb], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[0][kb], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[1][kb], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[1][kb], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[0][kb], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[0][kb], bh, acc, 0, 0, 0);
+    }
     }
     }
     // The loads issued above landed during the MFMA phase; retiring them HERE (vmcnt(0), free) lets the next
@@ -514,14 +577,19 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // rank-1 coefficient (KTGNN.py:277-280): -gate_s2t on source rows (table 0), +gate_t2s on target rows (table 1)
-      if (q == 0 || hsel[q] != hsel[q - 1]) {
-        const bool t1 = hsel[q] & 1;
-        cf = (sdom != t1) ? tanh_fast(pr[hsel[q]]) : 0.f;
-        cf = t1 ? cf : -cf;
+      if constexpr (MODE == 0) {
+        if (q == 0 || hsel[q] != hsel[q - 1]) {
+          const bool t1 = hsel[q] & 1;
+          cf = (sdom != t1) ? tanh_fast(pr[hsel[q]]) : 0.f;
+          cf = t1 ? cf : -cf;
+        }
       }
       float4 o;
       o.x = fmaf(cf, wv[q].x, acc[4 * q] + bv[q].x);     o.y = fmaf(cf, wv[q].y, acc[4 * q + 1] + bv[q].y);
       o.z = fmaf(cf, wv[q].z, acc[4 * q + 2] + bv[q].z); o.w = fmaf(cf, wv[q].w, acc[4 * q + 3] + bv[q].w);
+      if constexpr (MODE == 1) {
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      }
       *reinterpret_cast<float4*>(&cw[fr * CT_LD + 8 * q + 4 * fh]) = o;
     }
     // ... then a wave-private LDS transpose so every store instruction writes 8 rows x 128 contiguous bytes (whole
@@ -535,16 +603,160 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
 #if defined(GEMM_EXP) && (GEMM_EXP == 12 || GEMM_EXP == 14)
         if (v.x == 12345.678f)
 #endif
-        if (row < p.N) *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
+        if (row < p.N) {
+          *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
+          if constexpr (MODE == 1) {
+            if (p.colsum != nullptr) {            // per-lane fp32 partials (4 fixed columns, ~500 rows per lane and launch)
+              if (pre[cur][rs * 32 + (lane >> 3) + 8 * i][MAXH * 2] != 0.f) { cs_s.x += v.x; cs_s.y += v.y; cs_s.z += v.z; cs_s.w += v.w; n_s += 1.f; }
+              else { cs_t.x += v.x; cs_t.y += v.y; cs_t.z += v.z; cs_t.w += v.w; n_t += 1.f; }
+            }
+          }
+        }
       }
     }
     }
-#if !defined(GEMM_EXP) || (GEMM_EXP != 13 && GEMM_EXP != 14)
-    if constexpr (LATE) sstore(cur ^ 1);
-#endif
   }
+  if constexpr (MODE == 1) {
+    if (p.colsum != nullptr) {
+      // lanes -> block (ds_add_f32) -> one hardware fp64 atomic per (block, column, domain)
+      __shared__ float red[2][32 * NCT + 1];
+      for (int t = tid; t < 2 * (32 * NCT + 1); t += 64 * NW) (&red[0][0])[t] = 0.f;
+      __syncthreads();
+      const int lc = ct * 32 + 4 * (lane & 7);
+      unsafeAtomicAdd(&red[0][lc], cs_s.x); unsafeAtomicAdd(&red[0][lc + 1], cs_s.y);
+      unsafeAtomicAdd(&red[0][lc + 2], cs_s.z); unsafeAtomicAdd(&red[0][lc + 3], cs_s.w);
+      unsafeAtomicAdd(&red[1][lc], cs_t.x); unsafeAtomicAdd(&red[1][lc + 1], cs_t.y);
+      unsafeAtomicAdd(&red[1][lc + 2], cs_t.z); unsafeAtomicAdd(&red[1][lc + 3], cs_t.w);
+      if (ct == 0 && (lane & 7) == 0 && blockIdx.y == 0) { unsafeAtomicAdd(&red[0][32 * NCT], n_s); unsafeAtomicAdd(&red[1][32 * NCT], n_t); }
+      __syncthreads();
+      for (int t = tid; t < 2 * (32 * NCT + 1); t += 64 * NW) {
+        const int d = t / (32 * NCT + 1), c = t % (32 * NCT + 1);
+        const double sum = (double)red[d][c];
+        const int gc0 = blockIdx.y * (32 * NCT) + c;
+        if (c == 32 * NCT) { if (blockIdx.y == 0) unsafeAtomicAdd(&p.colsum[2 * p.NC + d], sum); }
+        else if (gc0 < p.NC) unsafeAtomicAdd(&p.colsum[d * p.NC + gc0], sum);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ skinny variant (NC <= 24 packed columns, Din <= 128)
+// KT-GNN's classifier convs have D = n_classes (2..10): the transform is a pure stream over x (HBM-bound, 0.09 ms for
+// 512 MB) and the 128-row block tiles of transform_gemm_kernel<32,...> run it at 2.7 TB/s.  Here every WAVE is
+// autonomous -- its own 32-row tile in a private LDS region, no block barrier, the next tile's loads in flight in
+// registers during the MFMA phase -- so the 8 waves of a CU drift apart and keep HBM busy.  The 32-column MFMA tile
+// has room for the gate vectors as well: rows 24..27 (and their copy 28..31, so both lane halves see them) of the
+// stationary operand hold g[h][t][:Din], which turns the four gate GEMVs into accumulator registers 12..15.
+template <int DK>
+__global__ __launch_bounds__(256) void transform_skinny_kernel(GemmParams p) {
+  constexpr int LD = DK + 4, KB = DK / 8, F4_ROW = DK / 4, NLD = 32 * F4_ROW / 64, RPL = 64 / F4_ROW;  // RPL rows per load instr
+  __shared__ __attribute__((aligned(16))) float xs[4][32 * LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  float* const xw = xs[wave];
+
+  float wreg[KB * 4];
+  {
+    const float* src = nullptr;               // row fr of the stationary operand
+    if (fr < p.NC) src = p.Wp + (int64_t)fr * p.Din;
+    else if (fr >= 24 && ((fr - 24) & 3) < 2 * p.n_heads) src = p.g + (int64_t)((fr - 24) & 3) * 2 * p.Din;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int k = 8 * kb + 4 * fh;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src != nullptr && k < p.Din) w = *reinterpret_cast<const float4*>(src + k);
+      wreg[4 * kb] = w.x; wreg[4 * kb + 1] = w.y; wreg[4 * kb + 2] = w.z; wreg[4 * kb + 3] = w.w;
+    }
+  }
+  // epilogue constants: accumulator registers 4q..4q+3 of a lane are columns 8q + 4fh + (0..3) of row fr (q < 3)
+  float4 bv[3], wv[3];
+  float* optr[3];
+  int hsel[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int c = 8 * q + 4 * fh;
+    bv[q] = wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    optr[q] = nullptr; hsel[q] = 0;
+    if (c < p.NC) {
+      const int ld2 = 2 * (int)p.ldh;
+      const int h = c / ld2, rem = c % ld2, t = rem >= p.ldh ? 1 : 0;
+      bv[q] = *reinterpret_cast<const float4*>(p.bias + c);
+      wv[q] = *reinterpret_cast<const float4*>(p.wd + c);
+      float* base = h == 0 ? (t == 0 ? p.out[0][0] : p.out[0][1]) : (t == 0 ? p.out[1][0] : p.out[1][1]);
+      optr[q] = base + (rem - t * (int)p.ldh);
+      hsel[q] = h * 2 + t;
+    }
+  }
+  float gcs[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) gcs[h] = h < 2 * p.n_heads ? p.gc[h] : 0.f;
+
+  const int c4 = lane % F4_ROW, lrow = lane / F4_ROW;
+  const bool kv = c4 * 4 < p.Din;
+  float4 ra[NLD];
+  uint8_t rm = 0;
+  auto gload = [&](int64_t tl) {              // branch-free (exact s_waitcnt counts): tail rows re-read row N-1
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      int64_t r = tl * 32 + lrow + RPL * j;
+      r = r < p.N ? r : p.N - 1;
+      float4 v = *reinterpret_cast<const float4*>(p.x + r * p.ldx + (kv ? c4 * 4 : 0));
+      if (!kv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[j] = v;
+    }
+    int64_t r = tl * 32 + fr;
+    rm = p.mask[r < p.N ? r : p.N - 1];
   };
-  if (wave >= NW / 2) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
+
+  const int64_t ntiles = (p.N + 31) / 32, last = ntiles - 1;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;                 // wave-uniform; the kernel has no block barrier
+  gload(tile);
+  for (; tile < ntiles; tile += stride) {
+    // registers -> this wave's LDS tile (the previous tile's reads completed before its MFMAs issued)
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) *reinterpret_cast<float4*>(&xw[(lrow + RPL * j) * LD + c4 * 4]) = ra[j];
+    const bool sdom = rm != 0;
+    gload(min(tile + stride, last));          // next tile flies during the MFMA phase (issuing the loads per tile
+                                              // instead -- 200 VGPRs, two waves per SIMD -- measured the same or slower)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xb = &xw[fr * LD + 4 * fh];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const float4 b = *reinterpret_cast<const float4*>(xb + 8 * kb);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb], b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 1], b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 2], b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * kb + 3], b.w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // retire the prefetch before the stores (see transform_wreg_kernel)
+    const int64_t row = tile * 32 + fr;
+    if (row < p.N) {
+      float cf = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (optr[q] != nullptr) {
+          if (q == 0 || hsel[q] != hsel[q - 1]) {
+            const bool t1 = hsel[q] & 1;
+            const float pre = hsel[q] == 0 ? acc[12] : hsel[q] == 1 ? acc[13] : hsel[q] == 2 ? acc[14] : acc[15];
+            const float gcv = hsel[q] == 0 ? gcs[0] : hsel[q] == 1 ? gcs[1] : hsel[q] == 2 ? gcs[2] : gcs[3];
+            cf = (sdom != t1) ? tanh_fast(pre + gcv) : 0.f;
+            cf = t1 ? cf : -cf;
+          }
+          float4 o;
+          o.x = fmaf(cf, wv[q].x, acc[4 * q] + bv[q].x);     o.y = fmaf(cf, wv[q].y, acc[4 * q + 1] + bv[q].y);
+          o.z = fmaf(cf, wv[q].z, acc[4 * q + 2] + bv[q].z); o.w = fmaf(cf, wv[q].w, acc[4 * q + 3] + bv[q].w);
+          *reinterpret_cast<float4*>(optr[q] + row * p.row_stride) = o;
+        }
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -595,7 +807,7 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
   GemmParams p;
   p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;
   p.out[0][0] = h_s2t_0; p.out[0][1] = h_t2s_0; p.out[1][0] = h_s2t_1; p.out[1][1] = h_t2s_1;
-  p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads;
+  p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads; p.relu = 0; p.colsum = nullptr;
   const int64_t nrt = (N + BM - 1) / BM;
   const int64_t nrt8 = (nrt + 7) / 8 * 8;        // row tiles rounded up to the XCD group size
   static const int n_cu = [] {
@@ -613,11 +825,19 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
     const int ncg = (NC + 32 * nct - 1) / (32 * nct);
     const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
     const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), (unsigned)ncg);
-#define BGNN_WREG(DK, NCT, NW) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW>), grid, dim3(64 * NW), 0, st, p)
+    static const bool bf3 = [] { const char* e = getenv("BGNN_GEMM_BF3"); return !e || atoi(e) != 0; }();
+#define BGNN_WREG(DK, NCT, NW) do { if (bf3 && NCT >= 4) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, true, 0>), grid, dim3(64 * NW), 0, st, p); \
+                                     else hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, false, 0>), grid, dim3(64 * NW), 0, st, p); } while (0)
 #define BGNN_WREG_DK(NCT, NW) do { if (Din <= 64) BGNN_WREG(64, NCT, NW); else BGNN_WREG(128, NCT, NW); } while (0)
     if (nct == 2) BGNN_WREG_DK(2, 4); else if (nct == 4) BGNN_WREG_DK(4, 8); else BGNN_WREG_DK(8, 8);
 #undef BGNN_WREG_DK
 #undef BGNN_WREG
+  } else if (use_wreg && NC <= 24 && Din <= 128) {
+    // wave-autonomous stream: two 4-wave blocks per CU, each wave strides over 32-row tiles
+    const int64_t nt = (N + 31) / 32, nb = (nt + 3) / 4;
+    const unsigned grid = (unsigned)(nb < 2 * n_cu ? nb : 2 * n_cu);
+    if (Din <= 64) hipLaunchKernelGGL((transform_skinny_kernel<64>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((transform_skinny_kernel<128>), dim3(grid), dim3(256), 0, st, p);
   } else if (NC <= 32) {
     hipLaunchKernelGGL((transform_gemm_kernel<32, 4, 1, 1, 1>), dim3((unsigned)nrt8), dim3(256), 0, st, p);
   } else if (NC <= 64) {
@@ -626,6 +846,40 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
     const int nct = (NC + 127) / 128;
     hipLaunchKernelGGL((transform_gemm_kernel<128, 2, 2, 2, 2>), dim3((unsigned)(nrt8 * nct)), dim3(256), 0, st, p);
   }
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,
+                               int32_t Dout, int relu, const uint8_t* mask_opt, double* colsum_opt,
+                               float* out, int64_t ldo, void* stream) {
+  if (!x || !W || !bias || !out || (colsum_opt && !mask_opt)) return BGNN_E_NULL;
+  // the W-stationary kernel's envelope: full 64-column groups, weights of a column tile in <= 96 registers
+  if (N < 0 || Din <= 0 || Din > 128 || (Din & 3) || (ldx & 3) || ldx < Din || Dout <= 0 || (Dout & 63) || ldo < Dout || (ldo & 3))
+    return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(W) || !bgnn_aligned16(bias) || !bgnn_aligned16(out)) return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p{};
+  p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask_opt; p.Wp = W; p.bias = bias; p.wd = nullptr; p.g = nullptr; p.gc = nullptr;
+  p.out[0][0] = out; p.out[0][1] = out; p.out[1][0] = out; p.out[1][1] = out;
+  p.ldh = Dout;            // one "table" spanning all columns: column c -> (h, t) = (0, 0), offset c
+  p.row_stride = ldo; p.NC = Dout; p.n_heads = 1; p.relu = relu; p.colsum = colsum_opt;
+  static const int n_cu = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }();
+  const int nct = Dout % 256 == 0 ? 8 : Dout % 128 == 0 ? 4 : 2;
+  const int nw = nct == 2 ? 4 : 8;
+  const int bmw = 32 * (nw / nct);
+  const int64_t ntiles = (N + bmw - 1) / bmw;
+  const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
+  const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), (unsigned)(Dout / (32 * nct)));
+#define BGNN_LIN(DK, NCT, NW, BF) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, BF, 1>), grid, dim3(64 * NW), 0, st, p)
+#define BGNN_LIN_DK(NCT, NW, BF) do { if (Din <= 64) BGNN_LIN(64, NCT, NW, BF); else BGNN_LIN(128, NCT, NW, BF); } while (0)
+  if (nct == 2) BGNN_LIN_DK(2, 4, false); else if (nct == 4) BGNN_LIN_DK(4, 8, true); else BGNN_LIN_DK(8, 8, true);
+#undef BGNN_LIN_DK
+#undef BGNN_LIN
   BGNN_LAUNCH_CHECK();
   return 0;
 }

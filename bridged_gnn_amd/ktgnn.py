@@ -322,20 +322,31 @@ class KTGNN_no_complement(nn.Module):
                 x = F.dropout(x, p=self.dropout, training=self.training)
         return (x, sums) if want_sums else x
 
-    def _transformer_hidden_eval(self, x):
-        """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded, ReLU in the GEMM epilogue when available)."""
+    def _transformer_hidden_eval(self, x, mask_u8=None, want_sums=False):
+        """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded: BN(Wx+b) = (s*W)x + (s*b + t)).  Inside the
+        envelope of `ops.linear` the W-stationary MFMA kernel applies bias + ReLU and, with `want_sums`, accumulates the
+        per-domain column sums of h1 in its epilogue; other shapes go through the library GEMM."""
         l0, bn, _, l3 = self.clf_transformer
         key = tuple((p.data_ptr(), p._version) for p in self.clf_transformer.parameters()) + \
             (bn.running_mean._version, bn.running_var._version)
         if getattr(self, "_tf_key", None) != key:
             s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
-            self._tf_w0t = (l0.weight.detach() * s[:, None]).t().contiguous()
-            self._tf_b0 = (l0.bias.detach() * s + bn.bias.detach() - bn.running_mean * s).contiguous()
+            self._tf_w0 = (l0.weight.detach() * s[:, None]).float().contiguous()
+            self._tf_w0t = self._tf_w0.t().contiguous()
+            self._tf_b0 = (l0.bias.detach() * s + bn.bias.detach() - bn.running_mean * s).float().contiguous()
             self._tf_key = key
             self._tf_pack = None
-        if hasattr(torch, "_addmm_activation"):
-            return torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
-        return F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
+        sums = None
+        dout, din = self._tf_w0.shape
+        if x.dtype == torch.float32 and x.stride(1) == 1 and ops.linear_supported(din, dout):
+            if want_sums:
+                sums = torch.zeros(2 * dout + 2, dtype=torch.float64, device=x.device)
+            h1 = ops.linear(x, self._tf_w0, self._tf_b0, relu=True, mask_u8=mask_u8 if want_sums else None, colsum=sums)
+        elif hasattr(torch, "_addmm_activation"):
+            h1 = torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
+        else:
+            h1 = F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
+        return (h1, sums) if want_sums else h1
 
     def _composed_target_pack(self, din_pad):
         """clf_target evaluated on x' = h1.W3^T + b3 without materialising x' (the last Linear of clf_transformer is
@@ -390,9 +401,9 @@ class KTGNN_no_complement(nn.Module):
             self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
             # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
             # h1 = relu(BN(Linear0(x))) is materialised
-            h1 = self._transformer_hidden_eval(x)
+            h1, sums1 = self._transformer_hidden_eval(x, mask_u8, want_sums=True)
             h1p = _pad_cols4(h1)
-            d1 = ops.domain_delta(ops.domain_sums(h1p, mask_u8), h1p.shape[1])
+            d1 = ops.domain_delta(sums1 if sums1 is not None else ops.domain_sums(h1p, mask_u8), h1p.shape[1])
             ops.adaptedconv_transform(h1p, mask_u8, d1, self._composed_target_pack(h1p.shape[1]), out=[views[2]])
             a_t2s = torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])
             a_s2t = torch.stack([c.a_f_s2t.weight.detach().reshape(-1) for c in (self.clf_base, self.clf_target, self.clf_target)])

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "pad4"]
 
 
@@ -60,6 +60,23 @@ def domain_delta(sums, Din):
     rc = L.lib().bgnn_domain_delta_f32(L.ptr(sums), Din, L.ptr(delta), L.stream())
     L.check(rc, "bgnn_domain_delta_f32")
     return delta
+
+
+def linear_supported(din, dout):
+    """envelope of `linear` (the W-stationary MFMA kernel): Din <= 128, Din % 4 == 0, Dout % 64 == 0."""
+    return din <= 128 and din % 4 == 0 and dout % 64 == 0
+
+
+def linear(x, weight, bias, relu=False, mask_u8=None, colsum=None):
+    """relu?(x @ weight.T + bias) (KTGNN.py:407-411/:433, clf_transformer's first Linear with eval BatchNorm folded in);
+    `colsum` (zeroed float64 [2*Dout+2], needs mask_u8) also receives the per-domain column sums of the result."""
+    N, din = x.shape
+    dout = weight.shape[0]
+    out = torch.empty(N, dout, dtype=torch.float32, device=x.device)
+    rc = L.lib().bgnn_linear_f32(L.ptr_rows(x), N, din, x.stride(0), L.ptr(weight), L.ptr(bias), dout, 1 if relu else 0,
+                                 L.ptr(mask_u8), L.ptr(colsum), L.ptr(out), dout, L.stream())
+    L.check(rc, "bgnn_linear_f32")
+    return out
 
 
 def pack_transform_heads(heads, din_pad):

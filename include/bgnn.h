@@ -73,6 +73,15 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
 int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
                          double* sums_io /*[2*Din+2]*/, void* stream);
 int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* delta, void* stream);
+/* bgnn_linear_f32: out = relu?(x W^T + bias) for the first Linear (+ folded eval BatchNorm + ReLU) of
+ *   KTGNN_no_complement.clf_transformer (models/KTGNN.py:407-411, applied at :433), on the same W-stationary MFMA kernel
+ *   as the transform; colsum_opt ([2*Dout+2], zeroed by the caller, needs mask_opt) additionally receives the per-domain
+ *   column sums + node counts of the OUTPUT, i.e. the domain sums (:275) of the conv that consumes it -- no extra pass.
+ *   W [Dout, Din] is torch Linear.weight layout.  Envelope: Din <= 128, Din % 4 == 0, Dout % 64 == 0 (else
+ *   BGNN_E_SHAPE; callers use a library GEMM outside it). */
+int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,
+                    int32_t Dout, int relu, const uint8_t* mask_opt, double* colsum_opt,
+                    float* out, int64_t ldo, void* stream);
 int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                    const uint8_t* mask, const float* delta,
                                    int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,

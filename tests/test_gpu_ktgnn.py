@@ -97,6 +97,49 @@ def test_adaptedconv_shapes_vs_c_oracle(din, D, n):
     assert_close(out.cpu().numpy(), ref, rtol=1e-5, atol_scale=2e-6, what=f"out din={din} D={D}")
 
 
+@pytest.mark.parametrize("din,D,n", [(128, 128, 5000), (64, 64, 4133), (100, 128, 2999), (128, 32, 3001), (96, 192, 1111),
+                                     (36, 96, 777)])
+def test_transform_w_stationary_kernel_shapes(din, D, n):
+    """the W-stationary MFMA transform (2*D % 64 == 0, Din <= 128; bf16x3 split products for >= 128 packed columns)
+    vs the C oracle: ragged last tile, Din % 8 != 0, several column groups."""
+    from bridged_gnn_amd.ktgnn import AdaptedConv, _as_u8
+    rng = np.random.default_rng(din * 1000 + D)
+    mask = rng.random(n) < 0.45
+    x = (rng.standard_normal((n, din)) * rng.choice([0.01, 1.0, 30.0], size=(n, 1))).astype(np.float32)
+    torch.manual_seed(din + D)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV).eval()
+    with torch.no_grad():
+        h_t2s, h_s2t = conv.transform(_t(x), _as_u8(_t(mask)))
+    prm = {k: v.cpu().numpy() for k, v in conv.state_dict().items()}
+    hs2t, ht2s = OC.adaptedconv_transform(x, mask, prm)
+    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=2e-6, what=f"h_t2s din={din} D={D}")
+    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=2e-6, what=f"h_s2t din={din} D={D}")
+
+
+@pytest.mark.parametrize("din,dout,n,relu", [(128, 128, 4097, True), (64, 64, 1000, False), (100, 256, 333, True), (128, 192, 2500, True)])
+def test_linear_relu_colsum(din, dout, n, relu):
+    """bgnn_linear_f32 (clf_transformer's first Linear + folded BN + ReLU, KTGNN.py:407-411) and its fused per-domain
+    column sums vs fp64 numpy."""
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(din + dout + n)
+    x = rng.standard_normal((n, din)).astype(np.float32)
+    W = (rng.standard_normal((dout, din)) / np.sqrt(din)).astype(np.float32)
+    b = rng.standard_normal(dout).astype(np.float32)
+    mask = rng.random(n) < 0.3
+    sums = torch.zeros(2 * dout + 2, dtype=torch.float64, device=DEV)
+    out = ops.linear(_t(x), _t(W), _t(b), relu=relu, mask_u8=_t(mask).to(torch.uint8), colsum=sums)
+    ref = x.astype(np.float64) @ W.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0.0)
+    assert_close(out.cpu().numpy(), ref, rtol=1e-5, atol_scale=2e-6, what="linear")
+    got = sums.cpu().numpy()
+    o64 = out.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got[:dout], o64[mask].sum(0), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(got[dout:2 * dout], o64[~mask].sum(0), rtol=1e-6, atol=1e-4)
+    assert got[2 * dout] == mask.sum() and got[2 * dout + 1] == (~mask).sum()
+    assert torch.equal(ops.linear(_t(x), _t(W), _t(b), relu=relu), out)      # sums are optional
+
+
 def test_root_weight_and_normalize_paths():
     from bridged_gnn_amd import ops, synth
     from bridged_gnn_amd.ktgnn import AdaptedConv

@@ -32,10 +32,10 @@ for exp in [int(a) for a in sys.argv[1:]] or [0, 1]:
         rc = fn(x.data_ptr(), N, Din, Din, mask.data_ptr(), delta.data_ptr(), 1, D, Wp.data_ptr(), bp.data_ptr(), gates.data_ptr(),
                 gconst.data_ptr(), o1.data_ptr(), o2.data_ptr(), None, None, ldh, ldh, small.data_ptr(), None)
         assert rc == 0, rc
-    for _ in range(3): call()
+    for _ in range(20): call()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(10):
+    for _ in range(40):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); call(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     print("GEMM_EXP", exp, "ms med", round(float(np.median(ts)), 3), "min", round(min(ts), 3), flush=True)
