@@ -15,6 +15,7 @@
 // Index results are therefore bit-identical to oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk.
 #include <cstdio>
 
+#include <cstdlib>
 #include "bgnn_common.h"
 
 namespace {
@@ -22,6 +23,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
 constexpr int WAVES = 4;
 constexpr int QPB = QPW * WAVES;   // queries per block
@@ -335,14 +338,40 @@ __device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, in
 // DK = d / 8.  Work = (query block, candidate tile) pairs, query-major; every persistent block takes one
 // CONTIGUOUS range of `tpb` tiles (perfect balance, no tail), emitting one shortlist per query-block
 // segment it touches (slot = block - first block touching that query block).
-template <int DK, int CAPV, int KPV>
+// BF3: the scores come from bf16 MFMAs on bf16 pieces of both operands (candidates hi + mid + lo = the fp32 significand,
+// queries hi + mid; five piece products).  fp32 MFMA shares the VALU datapath on CDNA (its 157 TFLOP/s
+// is the vector peak, and the shortlist upkeep's VALU work adds to it); the bf16 matrix cores are 16x faster and run
+// beside the VALU, so pass 1 becomes bound by the upkeep alone.  Candidates are split while they are staged
+// (fp32 in HBM/L2: no extra traffic), queries once per segment into registers.
+template <int D>
+__device__ __forceinline__ int bf_swz(int row) {          // 16-byte chunk swizzle of the unpadded bf16 piece rows
+  constexpr int NCH = D / 8;
+  if constexpr (NCH >= 16) return row & 15;
+  else if constexpr (NCH == 8) return (row >> 1) & 7;
+  else return (row >> 2) & 3;
+}
+__device__ __forceinline__ void bf_split4(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  const float vf[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)vf[e];
+    const float r1 = vf[e] - (float)hh;                   // exact
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+  }
+}
+
+template <int DK, int CAPV, int KPV, bool BF3>
 __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
                                                            int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
                                                            float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
   typedef WaveTopK<CAPV, KPV> TK;
   constexpr int D = DK * 8, LD = D + 4;
+  constexpr int NCH = D / 8;                                               // BF3: 16-byte chunks per piece row
+  constexpr size_t STAGE_BYTES = BF3 ? (size_t)3 * CT * D * 2 : sizeof(float) * CT * LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* stage = reinterpret_cast<float*>(smem);                           // [CT][LD]
+  float* stage = reinterpret_cast<float*>(smem);                           // fp32: [CT][LD]
+  __bf16* stage16 = reinterpret_cast<__bf16*>(smem);                       // BF3 : [3][CT][NCH ^ swizzle][8]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t ntiles = (Nc + CT - 1) / CT;
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
   const int64_t t_end = min(T, t + tpb);
 
   TK tk;
-  tk.carve(smem + sizeof(float) * CT * LD + (size_t)wave * TK::BYTES);
+  tk.carve(smem + STAGE_BYTES + (size_t)wave * TK::BYTES);
 #if defined(KNN_EXP) && KNN_EXP == 9
   if (lane < 8) tk.dbg[lane] = 0;
   const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
@@ -377,7 +406,16 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + 256 * j;
       const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) = pre[j];
+      if constexpr (!BF3) {
+        *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) = pre[j];
+      } else {
+        bf16x4 h, m, l;
+        bf_split4(pre[j], h, m, l);
+        const int off = (r * NCH + ((c4 >> 1) ^ bf_swz<D>(r))) * 8 + (c4 & 1) * 4;
+        *reinterpret_cast<bf16x4*>(&stage16[off]) = h;
+        *reinterpret_cast<bf16x4*>(&stage16[CT * D + off]) = m;
+        *reinterpret_cast<bf16x4*>(&stage16[2 * CT * D + off]) = l;
+      }
     }
   };
   const int fr = lane & 31, fh = lane >> 5;
@@ -397,12 +435,27 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
     const int64_t q0 = qb * QPB + wave * QPW;
     tk.init(lane);
     // B fragments (this wave's 32 queries): lane (j = lane&31, h = lane>>5) holds q[j][8kb + 4h + s], s = 0..3
-    float4 bq[DK];
+    float4 bq[BF3 ? 1 : DK];
+    bf16x8 bqp[BF3 ? 2 : 1][BF3 ? D / 16 : 1];   // BF3: lane (j, h) holds the (hi, mid) pieces of q[j][16kb + 8h + e], e = 0..7
+                                                 // (queries keep two pieces -- |q - hi - mid| <= 2^-18 |q| -- to stay within 256 VGPRs)
     {
       const int64_t gq = q0 + fr;
+      if constexpr (!BF3) {
 #pragma unroll
-      for (int kb = 0; kb < DK; ++kb)
-        bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kb = 0; kb < DK; ++kb)
+          bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < D / 16; ++kb)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float4 v = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 16 + fh * 8 + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bf16x4 h, m, l;
+            bf_split4(v, h, m, l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bqp[0][kb][4 * hf + e] = h[e]; bqp[1][kb][4 * hf + e] = m[e]; }
+          }
+      }
     }
     float tau = -INFINITY;
     gload(ct0);
@@ -415,17 +468,34 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* arow = &stage[fr * LD + fh * 4];
 #if defined(KNN_PRIO)
       __builtin_amdgcn_s_setprio(KNN_PRIO);
 #endif
+      if constexpr (!BF3) {
+        const float* arow = &stage[fr * LD + fh * 4];
 #pragma unroll
-      for (int kb = 0; kb < DK; ++kb) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
+        for (int kb = 0; kb < DK; ++kb) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
+        }
+      } else {
+        const int sw = bf_swz<D>(fr);
+#pragma unroll
+        for (int kb = 0; kb < D / 16; ++kb) {
+          const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&stage16[off]);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(&stage16[CT * D + off]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&stage16[2 * CT * D + off]);
+          // smallest terms first; dropped: lo*mid (2^-27) and the queries' lo piece (2^-18, in the error bound)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], acc, 0, 0, 0);
+        }
       }
 #if defined(KNN_PRIO)
       __builtin_amdgcn_s_setprio(0);
@@ -873,7 +943,7 @@ static int run_refine(const Canon& canon, int64_t Nq, int64_t Nc, int k, int KP,
   return 0;
 }
 
-template <int DK, int CAPV, int KPV>
+template <int DK, int CAPV, int KPV, bool BF3>
 static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, const TopkWs& w, int* nslots_out,
                                hipStream_t st) {
   constexpr int D = DK * 8, LD = D + 4;
@@ -896,8 +966,8 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
     return 0;
   }
 #endif
-  const size_t sh = sizeof(float) * CT * LD + WAVES * WaveTopK<CAPV, KPV>::BYTES;
-  auto kern = cosine_pass1_kernel<DK, CAPV, KPV>;
+  const size_t sh = (BF3 ? (size_t)3 * CT * D * 2 : sizeof(float) * CT * LD) + WAVES * WaveTopK<CAPV, KPV>::BYTES;
+  auto kern = cosine_pass1_kernel<DK, CAPV, KPV, BF3>;
   // immutable per (instantiation, device): how many blocks are co-resident.  The occupancy API prices LDS
   // against 64 KB per CU on ROCm 7.2 and answers 1 here; gfx950 has 160 KB per CU, and this kernel's
   // <= 256 VGPRs allow two waves per SIMD, so the residency is computed from those two budgets.
@@ -953,16 +1023,22 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   const int KP = pick_kp(k);
   int nsplit = 1;
   int rc;
-#define COS(DKV)                                                                                        \
-  rc = KP == KNN_KP_SMALL ? launch_cosine_pass1<DKV, KNN_CAP_SMALL, KNN_KP_SMALL>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st) \
-     : KP == 32 ? launch_cosine_pass1<DKV, 48, 32>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
-                : launch_cosine_pass1<DKV, 128, 64>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)
-  if (d == 32) { COS(4); } else if (d == 64) { COS(8); } else if (d == 128) { COS(16); } else { COS(32); }
+  static const bool bf3 = [] { const char* e = getenv("BGNN_KNN_BF3"); return !e || atoi(e) != 0; }();
+#define COS(DKV, BF)                                                                                    \
+  rc = KP == KNN_KP_SMALL ? launch_cosine_pass1<DKV, KNN_CAP_SMALL, KNN_KP_SMALL, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st) \
+     : KP == 32 ? launch_cosine_pass1<DKV, 48, 32, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
+                : launch_cosine_pass1<DKV, 128, 64, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)
+  if (d == 256) { COS(32, false); }            // 256-wide rows keep the fp32 MFMA path (LDS budget)
+  else if (bf3) { if (d == 32) { COS(4, true); } else if (d == 64) { COS(8, true); } else { COS(16, true); } }
+  else { if (d == 32) { COS(4, false); } else if (d == 64) { COS(8, false); } else { COS(16, false); } }
 #undef COS
   if (rc) return rc;
   // |fp32 MFMA dot - exact| <= d * 2^-24 * sum|a_c b_c| <= d * 2^-24 for unit vectors (Cauchy-Schwarz);
   // x2 safety + the fp32 rounding of the stored shortlist score
-  const double err_abs = 2.0 * (double)(d + 2) * 5.9604644775390625e-08;
+  // (bf16 path: query pieces exact to 2^-18 -> <= 2^-18 on the score of unit vectors; candidate pieces and the dropped
+  //  cross term < 2^-25; fp32 accumulation inside the MFMA possibly truncating, 2^-23 per add: 2^-18 + d 2^-23 = 1.9e-5
+  //  for d = 128 against err_abs = 4 (d + 2) 2^-24 = 3.1e-5)
+  const double err_abs = ((bf3 && d != 256) ? 4.0 : 2.0) * (double)(d + 2) * 5.9604644775390625e-08;
   CosineCanon canon{qn_query, qn_cand, d};
   return run_refine(canon, Nq, Nc, k, KP, nsplit, w, err_abs, 0.0, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
 }

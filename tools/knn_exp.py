@@ -22,7 +22,9 @@ dev = "cuda:0"
 q = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=0)).to(dev)
 c = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=1)).to(dev)
 qn = q / q.norm(dim=1, keepdim=True); cn = c / c.norm(dim=1, keepdim=True)
-for exp in (0, (("KNN_NO_PINGPONG", 1),)):
+def _parse(a):
+    return int(a) if a.isdigit() else tuple((kv.split('=')[0], kv.split('=')[1]) for kv in a.split(','))
+for exp in ([_parse(a) for a in sys.argv[1:]] or [0, 1]):
     lib = C.CDLL(build(exp))
     for name in ("bgnn_topk_workspace_bytes", "bgnn_cosine_topk_f32"):
         fn = getattr(lib, name); fn.restype, fn.argtypes = _lib.SIGNATURES[name]
