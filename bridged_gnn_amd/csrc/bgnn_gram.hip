@@ -1,0 +1,224 @@
+// Tall-skinny Gram product for the training path:  out[a][b] = sum_i A[i][a] * B[i][b]   (A [N,p], B [N,q], N ~ 1e6).
+//
+// Where it sits (reference Bridged-GNN/models/KTGNN.py:275-284 under autograd): the weight / gate gradients of the
+// AdaptedConv dense transform are  [G_s2t | G_t2s | dgate]^T . x  -- a [<=260, N] x [N, <=128] product whose reduction
+// dimension is the node count.  The library GEMM picks 16..32-row macro tiles for this shape (2 ms for 66 GFLOP); here
+// every persistent block streams its slice of the rows ONCE through LDS (coalesced 16-B loads, double buffered), keeps
+// the whole p x q result of its slice in MFMA accumulators (wave w owns output columns 32w..32w+31 and all <= 9 row
+// blocks: 144 VGPRs) and writes one partial; a second tiny kernel sums the partials in a fixed order (deterministic, no
+// atomics).  HBM-bound: (p + q) * 4 bytes per node, read once.
+#include "bgnn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GR_RT = 32;       // rows per LDS tile
+constexpr int GR_PA = 9;        // max 32-row blocks of the output (p <= 288)
+
+struct GramParams {
+  const float* A; int64_t lda; int32_t p;
+  const float* B; int64_t ldb; int32_t q;
+  int64_t N;
+  float* part;                  // [gridDim.x][p][q]
+};
+
+__global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][GR_RT][ldA + ldB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int pa = (g.p + 31) / 32;
+  const int ldA = pa * 32, ldB = 128 + ((pa & 1) ? 0 : 32);   // LDS rows, zero-filled past p / q; row stride = 32 (mod 64)
+  const int ldT = ldA + ldB;                                  // floats: the two rows of one MFMA step use disjoint banks
+  const int nA4 = g.p / 4, nB4 = g.q / 4;                // p, q % 4 == 0 (host)
+  const int64_t rows_per_blk = (g.N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(g.N, r0 + rows_per_blk);
+  const int ntile = r1 > r0 ? (int)((r1 - r0 + GR_RT - 1) / GR_RT) : 0;
+
+  // zero the padding columns once (they are never written by the staging loop)
+  for (int t = tid; t < 2 * GR_RT * ldT; t += 256) sm[t] = 0.f;
+  __syncthreads();
+
+  // staging: float4 slots of a tile = GR_RT * (nA4 + nB4), strided over the block; <= 13 per thread for p=260, q=128
+  const int n4 = nA4 + nB4, nslot = GR_RT * n4;
+  constexpr int MAXS = 13;
+  float4 st[MAXS];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+      const int s = tid + 256 * j;
+      st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s < nslot) {
+        const int r = s / n4, c = s % n4;
+        const int64_t row = r0 + (int64_t)t * GR_RT + r;
+        if (row < r1)
+          st[j] = c < nA4 ? *reinterpret_cast<const float4*>(g.A + row * g.lda + c * 4)
+                          : *reinterpret_cast<const float4*>(g.B + row * g.ldb + (c - nA4) * 4);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* base = sm + buf * GR_RT * ldT;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+      const int s = tid + 256 * j;
+      if (s < nslot) {
+        const int r = s / n4, c = s % n4;
+        float* d = base + r * ldT + (c < nA4 ? c * 4 : ldA + (c - nA4) * 4);
+        *reinterpret_cast<float4*>(d) = st[j];
+      }
+    }
+  };
+
+  f32x16 acc[GR_PA];
+#pragma unroll
+  for (int a = 0; a < GR_PA; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  const bool wave_on = wave * 32 < g.q;                  // wave-uniform
+
+  if (ntile > 0) { gload(0); sstore(0); }
+  if (ntile > 1) gload(1);
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    __syncthreads();                                     // tile t complete in `cur`; nobody reads cur^1 any more
+    if (t + 1 < ntile) sstore(cur ^ 1);
+    if (t + 2 < ntile) gload(t + 2);
+    if (wave_on) {
+      const float* base = sm + cur * GR_RT * ldT;
+#pragma unroll 4
+      for (int k = 0; k < GR_RT; k += 2) {
+        // D[i = A column][j = B column] += A[row k+fh][i] * B[row k+fh][j]
+        const float* rowp = base + (k + fh) * ldT;
+        const float b = rowp[ldA + wave * 32 + fr];
+#pragma unroll
+        for (int a = 0; a < GR_PA; ++a)
+          if (a < pa) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[a * 32 + fr], b, acc[a], 0, 0, 0);
+      }
+    }
+  }
+  // partial [p][q]: accumulator register r of lane (fr, fh) is D[i = (r&3) + 8(r>>2) + 4fh][j = fr]
+  if (wave_on) {
+    float* out = g.part + (int64_t)blockIdx.x * g.p * g.q;
+    const int col = wave * 32 + fr;
+#pragma unroll
+    for (int a = 0; a < GR_PA; ++a)
+      if (a < pa) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (i < g.p && col < g.q) out[(int64_t)i * g.q + col] = acc[a][r];
+        }
+      }
+  }
+}
+
+__global__ void gram_reduce_kernel(const float* __restrict__ part, int nblk, int64_t pq, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= pq) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * pq + e];    // fixed order: deterministic
+  out[e] = (float)s;
+}
+
+// persistent blocks: as many as fit a CU's 160 KB of LDS (up to 3) x 256 CUs
+static size_t gram_lds_bytes(int p) {
+  const int pa = (p + 31) / 32;
+  return sizeof(float) * 2 * GR_RT * (size_t)(pa * 32 + 128 + ((pa & 1) ? 0 : 32));
+}
+static int gram_blocks(int p) {
+  int per_cu = (int)((150 * 1024) / gram_lds_bytes(p));
+  per_cu = per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu;
+  return 256 * per_cu;
+}
+
+// out[i][j] = X[i,:d] . V[j,:d] for up to 4 vectors at once (gate pre-activations x.a_g and the gates' adjoints
+// G.(W delta) of the training path): one HBM stream over X instead of one library GEMV per vector (0.5 ms each).
+// 16 lanes own a row (float4 per lane and 64-column chunk), 4 rows per wave and step, 4 steps in flight.
+template <int NV>
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int d,
+                                                     const float* __restrict__ V, int64_t ldv, float* __restrict__ out) {
+  constexpr int MAXC = 4;                         // d <= 256
+  const int tid = threadIdx.x, l16 = tid & 15;
+  const int nch = (d + 63) / 64;
+  float4 v[NV][MAXC];
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int k = (c * 16 + l16) * 4;
+      v[j][c] = (c < nch && k < d) ? *reinterpret_cast<const float4*>(V + j * ldv + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const int64_t rows_per_pass = (int64_t)gridDim.x * 16;          // 16 rows per block and pass
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (tid >> 4); r < N; r += rows_per_pass) {
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int k = (c * 16 + l16) * 4;
+      if (c < nch && k < d) {
+        const float4 xv = *reinterpret_cast<const float4*>(X + r * ldx + k);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          acc[j] = fmaf(xv.x, v[j][c].x, acc[j]); acc[j] = fmaf(xv.y, v[j][c].y, acc[j]);
+          acc[j] = fmaf(xv.z, v[j][c].z, acc[j]); acc[j] = fmaf(xv.w, v[j][c].w, acc[j]);
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { const float t = bgnn::group_sum<16>(acc[j]); mine = l16 == j ? t : mine; }
+    if (l16 < NV) out[r * NV + l16] = mine;
+  }
+}
+
+}  // namespace
+
+extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
+                               float* out, void* stream) {
+  if (!X || !V || !out) return BGNN_E_NULL;
+  if (N < 0 || d <= 0 || d > 256 || (d & 3) || (ldx & 3) || (ldv & 3) || ldx < d || ldv < d || nv < 1 || nv > 4) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(X) || !bgnn_aligned16(V)) return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  int64_t grid = (N + 15) / 16;
+  if (grid > 4096) grid = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(rowdot_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
+    case 2: hipLaunchKernelGGL(rowdot_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
+    case 3: hipLaunchKernelGGL(rowdot_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
+    default: hipLaunchKernelGGL(rowdot_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
+  }
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t bgnn_gram_workspace_bytes(int32_t p, int32_t q) {
+  return sizeof(float) * (size_t)gram_blocks(p > 0 ? p : 1) * (size_t)(p > 0 ? p : 0) * (size_t)(q > 0 ? q : 0) + 256;
+}
+
+extern "C" int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float* B, int64_t ldb, int32_t q, int64_t N,
+                             float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !B || !out || !ws) return BGNN_E_NULL;
+  if (N < 0 || p <= 0 || q <= 0 || p > 32 * GR_PA || q > 128 || (p & 3) || (q & 3) || lda < p || ldb < q || (lda & 3) || (ldb & 3))
+    return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(A) || !bgnn_aligned16(B)) return BGNN_E_ALIGN;
+  if (ws_bytes < bgnn_gram_workspace_bytes(p, q)) return BGNN_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t pq = (int64_t)p * q;
+  int nblk = (int)((N + GR_RT - 1) / GR_RT);
+  if (nblk > gram_blocks(p)) nblk = gram_blocks(p);
+  if (nblk < 1) nblk = 1;
+  GramParams g{A, lda, p, B, ldb, q, N, (float*)ws};
+  const size_t sh = gram_lds_bytes(p);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_partial_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblk), dim3(256), sh, st, g);
+  BGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((pq + 255) / 256)), dim3(256), 0, st, (const float*)ws, nblk, pq, out);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}

@@ -9,8 +9,8 @@ What is different by design (MI355X-first, results identical within 1e-5 relativ
     kernel; the shifted copies x_s2t / x_t2s (:279-280) are never materialised;
   * eval-mode BatchNorm1d + ReLU after a hidden conv (:425-430) ride in that kernel's epilogue.
 Training: under autograd the fused aggregation is a `torch.autograd.Function`
-whose backward is the HIP kernel `bgnn_adaptedconv_aggregate_bwd_f32`; the dense transform then runs
-as plain torch ops (rocBLAS GEMMs) in the reference's op order so torch differentiates it.
+whose backward is the HIP kernel `bgnn_adaptedconv_aggregate_bwd_f32`; the dense transform is a second
+`torch.autograd.Function` (fused HIP forward, hand-derived backward = two library GEMMs + row reductions).
 """
 import math
 
@@ -84,6 +84,79 @@ class _AggregateFn(torch.autograd.Function):
         dh_t2s, dh_s2t, da_t2s, da_s2t = ops.adaptedconv_aggregate_bwd(
             h_t2s, h_s2t, a_t2s, a_s2t, ctx.csr, mask_u8, ctx.D, out, alpha, grad_out.contiguous(), ctx.slope)
         return dh_t2s, dh_s2t, da_t2s, da_s2t, None, None, None, None
+
+
+class _TransformFn(torch.autograd.Function):
+    """(h_t2s, h_s2t) = domain-shifted dense transform (KTGNN.py:275-284) through the fused HIP kernel; the backward is
+    written out by hand so that it is two plain GEMMs + row reductions instead of torch differentiating the
+    reference's op order ([N,2Din] concatenations, [N,Din] shifted copies, two skinny gate GEMVs and their adjoints):
+      S rows: h_s2t = W_t (x - g1 D) + b_t, h_t2s = W_s x + b_s;   T rows: h_s2t = W_t x + b_t, h_t2s = W_s (x + g2 D) + b_s
+      g = tanh(x.a_x + D.a_d) per gate,  D = mean_S x - mean_T x (a function of every row)."""
+
+    @staticmethod
+    def forward(ctx, x, W_s, b_s, W_t, b_t, ag_s2t, ag_t2s, mask_u8, conv):
+        xp = _pad_cols4(x)
+        din_pad = xp.shape[1]
+        sums = ops.domain_sums(xp, mask_u8)
+        delta = ops.domain_delta(sums, din_pad)
+        h_t2s, h_s2t = ops.adaptedconv_transform(xp, mask_u8, delta, conv.packed(din_pad))[0]
+        ctx.save_for_backward(x, W_s, W_t, ag_s2t, ag_t2s, mask_u8, delta, sums)
+        ctx.has_bias = (b_s is not None, b_t is not None)
+        return h_t2s, h_s2t
+
+    @staticmethod
+    def backward(ctx, G_t2s, G_s2t):
+        x, W_s, W_t, ag_s2t, ag_t2s, mask_u8, delta, sums = ctx.saved_tensors
+        N, din = x.shape
+        D = W_s.shape[0]
+        m = mask_u8.bool()
+        dl = delta[:din]
+        n_s, n_t = sums[-2].float(), sums[-1].float()
+        g1, g2 = ag_s2t.reshape(-1), ag_t2s.reshape(-1)
+        fast = x.stride(1) == 1 and x.stride(0) % 4 == 0 and din % 4 == 0 and x.data_ptr() % 16 == 0 and din <= 128 and D <= 128
+        # gate pre-activations: ONE stream over x for both gates (the library needs a 0.5 ms GEMV per vector, or a 2 ms
+        # GEMM with a 16-row macro tile for the [N,Din]x[Din,2] product)
+        Gx = torch.stack((g1[:din], g2[:din]))                                   # [2, Din]
+        pre = (ops.rowdot(x, Gx) if fast else x @ Gx.t()) + torch.stack((dl @ g1[din:], dl @ g2[din:]))
+        gam = torch.tanh(pre)
+        zero = gam.new_zeros(())
+        c1 = torch.where(m, gam[:, 0], zero)                                     # gate_s2t on source rows
+        c2 = torch.where(m, zero, gam[:, 1])                                     # gate_t2s on target rows
+        G1, G2 = G_s2t[:, :D], G_t2s[:, :D]
+        # Gall = [G1 | G2 | dpre1 | dpre2 | 0-pad]: every N-reduction below is a Gram product with Gall
+        p = ops.pad4(2 * D + 2)
+        Gall = x.new_zeros(N, p)
+        Gall[:, :D], Gall[:, D:2 * D] = G1, G2
+        wd = x.new_zeros(2, 2 * D)
+        wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
+        dc = ops.rowdot(Gall[:, :2 * D], wd) if fast and (2 * D) % 4 == 0 else Gall[:, :2 * D] @ wd.t()   # adjoints of the gates
+        dpre = torch.where(torch.stack((m, ~m), dim=1), dc * (1 - gam * gam), zero)
+        Gall[:, 2 * D:2 * D + 2] = dpre
+        side = torch.stack((c1, c2, torch.ones_like(c1), torch.zeros_like(c1)), dim=1)   # [N, 4]
+        if fast and ops.gram_supported(p, din):
+            dWall = ops.gram(Gall, x)                                            # [p, Din]  streaming Gram kernel
+            ex = torch.cat([ops.gram(side, Gall[:, c0:min(c0 + 128, p)]) for c0 in range(0, p, 128)], dim=1).t()   # [p, 4]
+        else:
+            dWall, ex = Gall.t() @ x, Gall.t() @ side
+        u1, u2 = ex[:D, 0], ex[D:2 * D, 1]                                      # sum_i gate_i G_i
+        sp = ex[2 * D:2 * D + 2, 2]                                             # sum_i dpre_i
+        dW_t = dWall[:D] - torch.outer(u1, dl)
+        dW_s = dWall[D:2 * D] + torch.outer(u2, dl)
+        dg1 = torch.cat((dWall[2 * D], sp[0] * dl))
+        dg2 = torch.cat((dWall[2 * D + 1], sp[1] * dl))
+        dX = None
+        if ctx.needs_input_grad[0]:
+            Wcat = x.new_zeros(p, din)                                          # rows: W_t, W_s, g1_x, g2_x
+            Wcat[:D], Wcat[D:2 * D], Wcat[2 * D], Wcat[2 * D + 1] = W_t, W_s, g1[:din], g2[:din]
+            ddl = sp[0] * g1[din:] + sp[1] * g2[din:] - W_t.t() @ u1 + W_s.t() @ u2
+            if ops.linear_supported(p, din):
+                dX = ops.linear(Gall, Wcat.t().contiguous(), x.new_zeros(din))  # skinny K: the W-stationary MFMA kernel
+            else:
+                dX = Gall @ Wcat
+            dX = dX + torch.where(m, 1.0 / n_s, -1.0 / n_t)[:, None] * ddl[None, :]   # through the domain means
+        db_s = ex[D:2 * D, 2] if ctx.has_bias[0] else None
+        db_t = ex[:D, 2] if ctx.has_bias[1] else None
+        return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None
 
 
 class AdaptedConv(nn.Module):
@@ -165,19 +238,10 @@ class AdaptedConv(nn.Module):
                                          ep_scale=sc, ep_shift=sh, ep_relu=relu, colsum=colsum)
 
     def _forward_autograd(self, x, mask, mask_u8, csr):
-        """Differentiable path: dense part in torch (reference op order, KTGNN.py:275-284), fused
-        aggregation through `_AggregateFn`."""
+        """Differentiable path: fused HIP transform + fused HIP aggregation, each a `torch.autograd.Function`."""
         D = self.out_channels
-        diff = x[mask].mean(0, keepdim=True) - x[~mask].mean(0, keepdim=True)                    # :275
-        diff = diff.expand(x.shape)
-        cat = torch.cat((x, diff), dim=-1)
-        shift_s2t = torch.tanh(self.a_g_s2t(cat)) * diff                                        # :277
-        shift_t2s = torch.tanh(self.a_g_t2s(cat)) * diff                                        # :278
-        h_s2t = self.lin_t(x - shift_s2t * mask.unsqueeze(-1))                                  # :279,:283
-        h_t2s = self.lin_s(x + shift_t2s * (~mask).unsqueeze(-1))                               # :280,:284
-        pad = ops.pad4(D) - D
-        if pad:
-            h_s2t, h_t2s = F.pad(h_s2t, (0, pad)), F.pad(h_t2s, (0, pad))
+        h_t2s, h_s2t = _TransformFn.apply(x, self.lin_s.weight, self.lin_s.bias, self.lin_t.weight, self.lin_t.bias,
+                                          self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self)
         out = _AggregateFn.apply(h_t2s, h_s2t, self.a_f_t2s.weight.reshape(-1), self.a_f_s2t.weight.reshape(-1),
                                  csr, mask_u8, D, self.negative_slope)
         return out[:, :D]

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "gram", "gram_supported", "rowdot",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "pad4"]
 
 
@@ -76,6 +76,34 @@ def linear(x, weight, bias, relu=False, mask_u8=None, colsum=None):
     rc = L.lib().bgnn_linear_f32(L.ptr_rows(x), N, din, x.stride(0), L.ptr(weight), L.ptr(bias), dout, 1 if relu else 0,
                                  L.ptr(mask_u8), L.ptr(colsum), L.ptr(out), dout, L.stream())
     L.check(rc, "bgnn_linear_f32")
+    return out
+
+
+def gram_supported(p, q):
+    return 0 < p <= 288 and 0 < q <= 128 and p % 4 == 0 and q % 4 == 0
+
+
+def gram(A, B):
+    """A^T B for tall-skinny row-major A [N,p], B [N,q] (the node count is the reduction dimension): the weight-gradient
+    products of the training path (KTGNN.py:275-284 under autograd)."""
+    N, p = A.shape
+    q = B.shape[1]
+    lib = L.lib()
+    wsb = lib.bgnn_gram_workspace_bytes(p, q)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
+    out = torch.empty(p, q, dtype=torch.float32, device=A.device)
+    rc = lib.bgnn_gram_f32(L.ptr_rows(A), A.stride(0), p, L.ptr_rows(B), B.stride(0), q, N, L.ptr(out), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_gram_f32")
+    return out
+
+
+def rowdot(X, V):
+    """X [N,d] (unit column stride, 16-B aligned rows) times up to four vectors V [nv,d] -> [N,nv] in one pass over X."""
+    N, d = X.shape
+    nv = V.shape[0]
+    out = torch.empty(N, nv, dtype=torch.float32, device=X.device)
+    rc = L.lib().bgnn_rowdot_f32(L.ptr_rows(X), X.stride(0), N, d, L.ptr(V), V.stride(0), nv, L.ptr(out), L.stream())
+    L.check(rc, "bgnn_rowdot_f32")
     return out
 
 

@@ -82,6 +82,17 @@ int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* 
 int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,
                     int32_t Dout, int relu, const uint8_t* mask_opt, double* colsum_opt,
                     float* out, int64_t ldo, void* stream);
+/* bgnn_gram_f32: out[a][b] = sum_i A[i][a] * B[i][b] for tall-skinny A [N,p], B [N,q] (p <= 288, q <= 128, both % 4 == 0).
+ *   The training path's weight / gate gradients of the dense transform (KTGNN.py:275-284 under autograd) are
+ *   [G_s2t | G_t2s | dgate]^T . x with the node count as the reduction dimension; one streaming pass, deterministic
+ *   two-stage sum.  ws: bgnn_gram_workspace_bytes(p, q). */
+size_t bgnn_gram_workspace_bytes(int32_t p, int32_t q);
+int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float* B, int64_t ldb, int32_t q, int64_t N,
+                  float* out /*[p][q]*/, void* ws, size_t ws_bytes, void* stream);
+/* bgnn_rowdot_f32: out[i][j] = X[i,:d] . V[j,:d], j < nv <= 4, d <= 256 (gate pre-activations and gate adjoints of the
+ *   training path): one stream over X for all vectors. */
+int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
+                    float* out /*[N][nv]*/, void* stream);
 int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                    const uint8_t* mask, const float* delta,
                                    int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,

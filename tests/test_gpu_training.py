@@ -45,6 +45,30 @@ def test_adaptedconv_gradients_vs_autograd_oracle(din, D, n):
         assert _rel(prm.grad.cpu().double(), p[name].grad) < 2e-4, name
 
 
+@pytest.mark.parametrize("p,q,n", [(260, 128, 5000), (8, 128, 3333), (36, 4, 1025), (288, 64, 700), (4, 4, 5)])
+def test_gram_kernel_vs_fp64(p, q, n):
+    """bgnn_gram_f32 (A^T B over the node dimension; weight gradients of the dense transform) vs fp64."""
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(p * q + n)
+    A = rng.standard_normal((n, p)).astype(np.float32)
+    B = rng.standard_normal((n, q)).astype(np.float32)
+    got = ops.gram(_t(A), _t(B)).cpu().double()
+    ref = torch.from_numpy(A).double().t() @ torch.from_numpy(B).double()
+    assert _rel(got, ref) < 1e-5
+    assert torch.equal(ops.gram(_t(A), _t(B)).cpu().double(), got), "deterministic"
+
+
+@pytest.mark.parametrize("d,nv,n", [(128, 2, 4097), (256, 2, 1000), (36, 4, 777), (4, 1, 3)])
+def test_rowdot_kernel_vs_fp64(d, nv, n):
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(d + nv + n)
+    X = rng.standard_normal((n, d + 4)).astype(np.float32)
+    V = rng.standard_normal((nv, d)).astype(np.float32)
+    got = ops.rowdot(_t(X)[:, :d], _t(V)).cpu().double()               # a column-slice view (row stride d + 4)
+    ref = torch.from_numpy(X[:, :d]).double() @ torch.from_numpy(V).double().t()
+    assert _rel(got, ref) < 1e-5
+
+
 def test_training_steps_follow_the_autograd_oracle():
     """3 Adam steps of the reference recipe (lr 1e-3, wd 5e-3, loss of main_graph_knowledge_transfer.py:44-54),
     dropout off, BN in train mode: loss trajectory and final weights vs the CPU torch oracle model."""
