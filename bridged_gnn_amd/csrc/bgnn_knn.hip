@@ -25,6 +25,10 @@ typedef unsigned long long u64;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#ifndef KNN_CAND_PIECES
+#define KNN_CAND_PIECES 2
+#endif
+constexpr int CPIECES = KNN_CAND_PIECES;   // bf16 pieces per candidate value (3 = full fp32 significand, 2 = 2^-18)
 constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
 constexpr int WAVES = 4;
 constexpr int QPB = QPW * WAVES;   // queries per block
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
   typedef WaveTopK<CAPV, KPV> TK;
   constexpr int D = DK * 8, LD = D + 4;
   constexpr int NCH = D / 8;                                               // BF3: 16-byte chunks per piece row
-  constexpr size_t STAGE_BYTES = BF3 ? (size_t)3 * CT * D * 2 : sizeof(float) * CT * LD;
+  constexpr size_t STAGE_BYTES = BF3 ? (size_t)CPIECES * CT * D * 2 : sizeof(float) * CT * LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stage = reinterpret_cast<float*>(smem);                           // fp32: [CT][LD]
   __bf16* stage16 = reinterpret_cast<__bf16*>(smem);                       // BF3 : [3][CT][NCH ^ swizzle][8]
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
         const int off = (r * NCH + ((c4 >> 1) ^ bf_swz<D>(r))) * 8 + (c4 & 1) * 4;
         *reinterpret_cast<bf16x4*>(&stage16[off]) = h;
         *reinterpret_cast<bf16x4*>(&stage16[CT * D + off]) = m;
-        *reinterpret_cast<bf16x4*>(&stage16[2 * CT * D + off]) = l;
+        if constexpr (CPIECES > 2) *reinterpret_cast<bf16x4*>(&stage16[2 * CT * D + off]) = l;
       }
     }
   };
@@ -488,10 +492,12 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
           const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&stage16[off]);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(&stage16[CT * D + off]);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&stage16[2 * CT * D + off]);
-          // smallest terms first; dropped: lo*mid (2^-27) and the queries' lo piece (2^-18, in the error bound)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
+          // smallest terms first; dropped pieces are in the error bound (2^-18 per operand with two pieces)
+          if constexpr (CPIECES > 2) {
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&stage16[2 * CT * D + off]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
+          }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], acc, 0, 0, 0);
@@ -526,6 +532,129 @@ __global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restri
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_knn_blk[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid; }
   if (lane < 8) atomicAdd(&g_knn_cnt[lane], tk.dbg[lane]);
 #endif
+}
+
+// pass 1, cosine, bf16 pieces, NW waves per block (NW * 32 queries) and a DOUBLE-BUFFERED candidate stage: one block
+// barrier per tile instead of two, and with NW = 8 (one block per CU) the staging work (global loads, bf16 split, LDS
+// writes) and the candidate traffic per query are half of the 4-wave form.  A wave that is busy with shortlist upkeep
+// holds the others up only when it falls a whole tile behind.
+template <int DK, int CAPV, int KPV, int NW>
+__global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
+                                                                  int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
+                                                                  float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+  typedef WaveTopK<CAPV, KPV> TK;
+  constexpr int D = DK * 8, NCH = D / 8, NT = 64 * NW, QB = NW * QPW;
+  constexpr int STAGE_ELEMS = CPIECES * CT * D;                             // bf16 elements per buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* stage16 = reinterpret_cast<__bf16*>(smem);                       // [2][CPIECES][CT][NCH ^ swizzle][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (Nc + CT - 1) / CT;
+  const int64_t nqb = (Nq + QB - 1) / QB;
+  const int64_t T = nqb * ntiles;
+  int64_t t = (int64_t)blockIdx.x * tpb;
+  const int64_t t_end = min(T, t + tpb);
+  TK tk;
+  tk.carve(smem + (size_t)2 * STAGE_ELEMS * 2 + (size_t)wave * TK::BYTES);
+
+  constexpr int F4_PER_ROW = D / 4, F4_TILE = CT * F4_PER_ROW;
+  constexpr int NLD = (F4_TILE + NT - 1) / NT;
+  float4 pre[NLD];
+  auto gload = [&](int64_t ct) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + NT * j;
+      const int r = (f / F4_PER_ROW) % CT, c4 = f % F4_PER_ROW;   // (f >= F4_TILE only for tiny D: harmless duplicate)
+      const int64_t gc = ct * CT + r;
+      pre[j] = gc < Nc ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](int buf) {
+    __bf16* st = stage16 + buf * STAGE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = tid + NT * j;
+      if (F4_TILE % NT == 0 || f < F4_TILE) {
+        const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+        bf16x4 h, m, l;
+        bf_split4(pre[j], h, m, l);
+        const int off = (r * NCH + ((c4 >> 1) ^ bf_swz<D>(r))) * 8 + (c4 & 1) * 4;
+        *reinterpret_cast<bf16x4*>(&st[off]) = h;
+        *reinterpret_cast<bf16x4*>(&st[CT * D + off]) = m;
+        if constexpr (CPIECES > 2) *reinterpret_cast<bf16x4*>(&st[2 * CT * D + off]) = l;
+      }
+    }
+  };
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sw = bf_swz<D>(fr);
+
+  while (t < t_end) {                               // block-uniform: one segment per query block touched
+    const int64_t qb = t / ntiles, ct0 = t % ntiles;
+    const int64_t ct1 = min(ntiles, ct0 + (t_end - t));
+    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
+    const int64_t q0 = qb * QB + wave * QPW;
+    tk.init(lane);
+    bf16x8 bqp[2][D / 16];                          // (hi, mid) pieces of q[j][16kb + 8h + e]
+    {
+      const int64_t gq = q0 + fr;
+#pragma unroll
+      for (int kb = 0; kb < D / 16; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float4 v = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 16 + fh * 8 + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          bf16x4 h, m, l;
+          bf_split4(v, h, m, l);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bqp[0][kb][4 * hf + e] = h[e]; bqp[1][kb][4 * hf + e] = m[e]; }
+        }
+    }
+    float tau = -INFINITY;
+    __syncthreads();                                // the previous segment's last tile has been read by every wave
+    gload(ct0);
+    sstore(0);
+    if (ct0 + 1 < ct1) gload(ct0 + 1);
+    // score one tile from stage[cur] on the matrix cores
+    auto score = [&](int cur) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const __bf16* st = stage16 + cur * STAGE_ELEMS;
+#pragma unroll
+      for (int kb = 0; kb < D / 16; ++kb) {
+        const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&st[off]);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(&st[CT * D + off]);
+        if constexpr (CPIECES > 2) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&st[2 * CT * D + off]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], acc, 0, 0, 0);
+      }
+      return acc;
+    };
+    auto offer = [&](const f32x16& acc, int64_t ct) {
+#if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
+      asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
+#else
+      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
+#endif
+    };
+    // (Letting the second wave of every SIMD do the upkeep of tile t-1 BEFORE it scores tile t -- so one wave feeds the
+    //  matrix pipe while its partner has the VALU -- measured 12.8 vs 12.2 ms: the upkeep is latency-bound, not issue-bound.)
+    int cur = 0;
+    for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
+      __syncthreads();                              // stage[cur] complete; nobody reads stage[cur^1] (tile ct-1) any more
+      if (ct + 1 < ct1) sstore(cur ^ 1);            // tile ct+1: registers -> the free buffer
+      if (ct + 2 < ct1) gload(ct + 2);              // tile ct+2 flies while this one is scored
+      const f32x16 acc = score(cur);
+      offer(acc, ct);
+    }
+    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
+    t += ct1 - ct0;
+  }
 }
 
 // (EXPERIMENT, compiled in but only launched with -DKNN_PINGPONG: slower than the default on MI355X)
@@ -966,7 +1095,22 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
     return 0;
   }
 #endif
-  const size_t sh = (BF3 ? (size_t)3 * CT * D * 2 : sizeof(float) * CT * LD) + WAVES * WaveTopK<CAPV, KPV>::BYTES;
+  static const int db_nw = [] { const char* e = getenv("BGNN_KNN_DB"); return e ? atoi(e) : 8; }();   // 0 = two-barrier 4-wave form
+  if constexpr (BF3) {
+    constexpr size_t sh8 = (size_t)2 * CPIECES * CT * D * 2 + 8 * WaveTopK<CAPV, KPV>::BYTES;
+    if (db_nw == 8 && sh8 <= 160 * 1024) {
+      auto k8 = cosine_pass1_db_kernel<DK, CAPV, KPV, 8>;
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh8);
+      if (attr != hipSuccess) return (int)attr;
+      const Pass1Plan pl = plan_pass1(Nq, Nc, prop.multiProcessorCount, 2 * QPB);     // one 8-wave block per CU
+      *nslots_out = pl.nslots;
+      if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k8, dim3((unsigned)pl.nblocks), dim3(512), sh8, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
+      BGNN_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const size_t sh = (BF3 ? (size_t)CPIECES * CT * D * 2 : sizeof(float) * CT * LD) + WAVES * WaveTopK<CAPV, KPV>::BYTES;
   auto kern = cosine_pass1_kernel<DK, CAPV, KPV, BF3>;
   // immutable per (instantiation, device): how many blocks are co-resident.  The occupancy API prices LDS
   // against 64 KB per CU on ROCm 7.2 and answers 1 here; gfx950 has 160 KB per CU, and this kernel's
@@ -1035,10 +1179,12 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   if (rc) return rc;
   // |fp32 MFMA dot - exact| <= d * 2^-24 * sum|a_c b_c| <= d * 2^-24 for unit vectors (Cauchy-Schwarz);
   // x2 safety + the fp32 rounding of the stored shortlist score
-  // (bf16 path: query pieces exact to 2^-18 -> <= 2^-18 on the score of unit vectors; candidate pieces and the dropped
-  //  cross term < 2^-25; fp32 accumulation inside the MFMA possibly truncating, 2^-23 per add: 2^-18 + d 2^-23 = 1.9e-5
-  //  for d = 128 against err_abs = 4 (d + 2) 2^-24 = 3.1e-5)
-  const double err_abs = ((bf3 && d != 256) ? 4.0 : 2.0) * (double)(d + 2) * 5.9604644775390625e-08;
+  // bf16 path: an operand kept as two pieces is exact to 2^-18 relative, as three pieces to 2^-27; for unit vectors the
+  // score error is <= (sum of the operands' piece errors + the dropped mid*mid term 2^-18) + d 2^-23 for the fp32
+  // accumulation inside the MFMA (counted as truncating).  Two pieces on both sides: 3 * 2^-18 + d 2^-23 = 2.7e-5 at
+  // d = 128; err_abs = 2^-16 + 4 (d + 2) 2^-24 = 4.6e-5 keeps a factor ~2 of safety like the fp32 bound does.
+  const double err_abs = (bf3 && d != 256) ? (CPIECES > 2 ? 0.0 : 1.52587890625e-05) + 4.0 * (double)(d + 2) * 5.9604644775390625e-08
+                                           : 2.0 * (double)(d + 2) * 5.9604644775390625e-08;
   CosineCanon canon{qn_query, qn_cand, d};
   return run_refine(canon, Nq, Nc, k, KP, nsplit, w, err_abs, 0.0, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
 }
