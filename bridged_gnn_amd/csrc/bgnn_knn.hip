@@ -556,6 +556,10 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
   const int64_t t_end = min(T, t + tpb);
   TK tk;
   tk.carve(smem + (size_t)2 * STAGE_ELEMS * 2 + (size_t)wave * TK::BYTES);
+#if defined(KNN_EXP) && KNN_EXP == 9
+  if (lane < 8) tk.dbg[lane] = 0;
+  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   constexpr int F4_PER_ROW = D / 4, F4_TILE = CT * F4_PER_ROW;
   constexpr int NLD = (F4_TILE + NT - 1) / NT;
@@ -642,19 +646,35 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
       offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
 #endif
     };
-    // (Letting the second wave of every SIMD do the upkeep of tile t-1 BEFORE it scores tile t -- so one wave feeds the
-    //  matrix pipe while its partner has the VALU -- measured 12.8 vs 12.2 ms: the upkeep is latency-bound, not issue-bound.)
+    // Cycle stamps (-DKNN_EXP=9, tools/knn_exp.py) per wave and tile: scoring 1530 (two waves share a SIMD's matrix pipe:
+    // 2 x 768), staging 660, barrier wait 1350, shortlist upkeep 1670 (queueing 980, drains 690 of which compaction 520).
+    // Negative results: letting the second wave of every SIMD do the upkeep of tile t-1 BEFORE it scores tile t (12.8 vs
+    // 12.2 ms) and parking single passes in per-lane registers until the next drain (12.5 ms) -- neither overlaps the
+    // matrix pipe with the VALU work in practice.
     int cur = 0;
     for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
+      KSTAMP(s0);
       __syncthreads();                              // stage[cur] complete; nobody reads stage[cur^1] (tile ct-1) any more
+      KSTAMP(s1);
       if (ct + 1 < ct1) sstore(cur ^ 1);            // tile ct+1: registers -> the free buffer
       if (ct + 2 < ct1) gload(ct + 2);              // tile ct+2 flies while this one is scored
+      KSTAMP(s2);
       const f32x16 acc = score(cur);
+#if defined(KNN_EXP) && KNN_EXP == 9
+      asm volatile("s_nop 0" ::"v"(acc[15]));
+#endif
+      KSTAMP(s3);
       offer(acc, ct);
+      KSTAMP(s4);
+      KACC(2, s0, s1); KACC(1, s1, s2); KACC(0, s2, s3); KACC(3, s3, s4);
     }
     emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
     t += ct1 - ct0;
   }
+#if defined(KNN_EXP) && KNN_EXP == 9
+  if (lane == 0) { tk.dbg[6] = __builtin_amdgcn_s_memtime() - kt0; tk.dbg[7] = __builtin_amdgcn_s_memrealtime() - kr0; }
+  if (lane < 8) atomicAdd(&g_knn_cnt[lane], tk.dbg[lane]);
+#endif
 }
 
 // (EXPERIMENT, compiled in but only launched with -DKNN_PINGPONG: slower than the default on MI355X)
