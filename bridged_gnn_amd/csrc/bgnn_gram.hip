@@ -117,8 +117,17 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int nblk, int64_t pq, float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= pq) return;
+  // fixed order (deterministic); 8 independent loads in flight per thread instead of a chain of nblk dependent ones
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * pq + e];    // fixed order: deterministic
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u) * pq + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; b < nblk; ++b) s += (double)part[(int64_t)b * pq + e];
   out[e] = (float)s;
 }
 

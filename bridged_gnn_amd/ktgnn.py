@@ -23,6 +23,30 @@ from . import ops
 __all__ = ["Linear", "AdaptedConv", "KTGNN_no_complement"]
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the weight gradient dY^T x on the streaming Gram kernel (ops.gram): for [N ~ 1e6, <= 128]
+    operands the library GEMM reduces over N with 32-row macro tiles (1.8 ms on C4 vs 0.3 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                  and x.data_ptr() % 16 == 0 and ops.gram_supported(gy.shape[1], x.shape[1]) and x.shape[0] >= 4096)
+            gw = ops.gram(gy, x) if ok else gy.t() @ x
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 class Linear(nn.Module):
     """Stand-in for `torch_geometric.nn.dense.linear.Linear` (used at KTGNN.py:240-246, :364-367):
     y = x W^T (+ b), weight [out, in]; kaiming-uniform(a=sqrt(5)) / 'glorot' initialisers."""
@@ -52,6 +76,8 @@ class Linear(nn.Module):
                 nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and self.weight.requires_grad:
+            return _LinearFn.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
 

@@ -148,6 +148,21 @@ int bgnn_adaptedconv_aggregate_bwd_f32(const float* h_t2s, const float* h_s2t, i
                                        float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
                                        void* stream);
 
+/* Atomic-free ("pull") form of the same backward for 32 < D <= 128: the source-side sums are gathered over a by-source
+ * view of the edges (t_rowptr [N+1]; t_eid [E'] = position of the edge in the by-destination order; t_dst [E'] = its
+ * destination) instead of scattered with float atomics; every dH row is written exactly once (no zero-fill needed,
+ * deterministic).  All N rows are visited; ws: bgnn_aggregate_bwd_pull_workspace_bytes(N, E', ldh). */
+size_t bgnn_aggregate_bwd_pull_workspace_bytes(int64_t N, int64_t E, int64_t ldh);
+int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                            const float* a_t2s, const float* a_s2t,
+                                            const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                            const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                                            int64_t N, int64_t E, int32_t D, float negative_slope,
+                                            const float* out, int64_t ldo, const float* alpha,
+                                            const float* grad_out, int64_t ldg,
+                                            float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                            void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a2,a3,a5,a6,a7) kNN bridge: pair scoring + per-query top-k.
  *     main_bridged_graph.py:45-67 / :90-111 (batched loop), models/models.py:124-130,:944-954
