@@ -768,9 +768,12 @@ extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int6
   if (!bgnn_aligned16(x)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = DS_NT / cw;
-  int64_t grid = (N + 255) / 256;
+  // 2*Din device-scope fp64 atomics per block at ~3 G/s: a block must stream >= 2048 rows to amortise them (a rank's
+  // share of a partitioned graph is small), and never more blocks than CUs
+  int64_t grid = (N + 2047) / 2048;
   static const int64_t gcap = [] { const char* e = getenv("BGNN_DS_GRID"); return e ? atoll(e) : 256ll; }();
   if (grid > gcap) grid = gcap;
+  if (grid < 1) grid = 1;
   hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(DS_NT), sizeof(double) * rl * 2 * cw * 4,
                      (hipStream_t)stream, x, N, Din, ldx, mask, sums_io);
   BGNN_LAUNCH_CHECK();

@@ -284,9 +284,8 @@ class PartitionedKTGNN:
         s_h = None
         for ind, conv in enumerate(m.convs):
             if m.use_bn:
-                bn = m.bns[ind]
-                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
-                sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
+                from .ktgnn import bn_eval_affine
+                sc, sh = bn_eval_affine(m.bns[ind])
                 last = ind == len(m.convs) - 1
                 # fused sums in the epilogue (one pass fewer over the rank-local activations; neutral on one GPU)
                 s_h = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=self.device) if last else None
@@ -299,10 +298,13 @@ class PartitionedKTGNN:
         # sums travel in ONE all-reduce
         from . import ops
         from .ktgnn import _pad_cols4
-        xt = m._transformer_hidden_eval(x).contiguous()   # h1; T's last Linear is folded into the conv weights
+        # h1; T's last Linear is folded into the conv weights; its rank-local domain sums come out of the GEMM epilogue
+        xt, s_t = m._transformer_hidden_eval(x, self.mask_u8, want_sums=True)
+        xt = xt.contiguous()
         if s_h is None:
             s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
-        s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
+        if s_t is None or s_t.numel() != 2 * _pad_cols4(xt).shape[1] + 2:
+            s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
         both = torch.cat((s_h, s_t))
         if self.world > 1 or self.always:
             both = self._all_reduce(both)

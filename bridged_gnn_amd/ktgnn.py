@@ -85,6 +85,19 @@ def _as_u8(mask):
     return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
 
 
+def bn_eval_affine(bn, cache_owner=None):
+    """BatchNorm1d(eval) as y = x * scale + shift; cached per parameter / buffer version (five tiny kernels per forward
+    otherwise -- they matter once a rank's share of the graph is small)."""
+    key = (bn.weight.data_ptr(), bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.running_mean.data_ptr(), bn.weight.device)
+    cached = getattr(bn, "_bgnn_affine", None)
+    if cached is None or cached[0] != key:
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
+        sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
+        bn._bgnn_affine = cached = (key, sc, sh)
+    return cached[1], cached[2]
+
+
 def _pad_cols4(t):
     """zero-pad the last dim to a multiple of 4 (float4 loads in the kernels)."""
     pad = (-t.shape[-1]) % 4
@@ -398,9 +411,7 @@ class KTGNN_no_complement(nn.Module):
         for ind, conv in enumerate(self.convs):                                   # :418-430
             sums_in, sums = sums, None
             if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters())):
-                bn = self.bns[ind]
-                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
-                sh = (bn.bias - bn.running_mean * sc).detach().float().contiguous()
+                sc, sh = bn_eval_affine(self.bns[ind])
                 if not (conv.root_weight or conv.normalize):
                     sums = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=x.device)
                 x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
