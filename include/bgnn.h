@@ -55,9 +55,11 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
  * bgnn_adaptedconv_transform_f32:                                               (:277-284)
  *   gate_s = tanh(x.g_s2t[:Din] + delta.g_s2t[Din:]),  gate_t likewise with g_t2s
  *   h_s2t = lin_t(x - gate_s*delta*[i in S]) ; h_t2s = lin_s(x + gate_t*delta*[i in T])
- *   evaluated by linearity as  W x + b -/+ gate * (W delta)  in ONE pass over x (fp32 MFMA
- *   v_mfma_f32_32x32x2_f32; the gate GEMVs ride in the staging loads, the rank-1 shift in the
- *   epilogue).  Up to n_heads = 2 convs that share the input x (clf_base / clf_target,
+ *   evaluated by linearity as  W x + b -/+ gate * (W delta)  in ONE pass over x (the gate GEMVs ride in the staging
+ *   loads, the rank-1 shift in the epilogue).  Products: for >= 128 packed columns and Din <= 128 every fp32 operand is
+ *   split exactly into three bf16 pieces and a product is the six piece MFMAs >= 2^-24 relative
+ *   (v_mfma_f32_32x32x16_bf16, fp32 accumulate; ~2e-7 relative to fp32 arithmetic); other shapes use
+ *   v_mfma_f32_32x32x2_f32.  tanh of the gates: exp/rcp form, absolute error < 5e-7.  Up to n_heads = 2 convs that share the input x (clf_base / clf_target,
  *   KTGNN.py:432,:434) are evaluated together.
  *   Wp     [n_heads*2*ldh, Din] packed weights: per head ldh rows of lin_t.weight (rows >= D zero)
  *          followed by ldh rows of lin_s.weight (torch Linear.weight layout [out, in]);
