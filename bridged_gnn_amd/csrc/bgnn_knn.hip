@@ -619,24 +619,29 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
     if (ct0 + 1 < ct1) gload(ct0 + 1);
     // score one tile from stage[cur] on the matrix cores
     auto score = [&](int cur) {
-      f32x16 acc;
+      // two independent accumulator chains (even / odd k blocks): a single dependent chain of 32x32x16 bf16 MFMAs issues
+      // one instruction per 64 cycles, half the matrix pipe's rate (tools/micro/mfma_valu_overlap.hip)
+      f32x16 acc, acc2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
       const __bf16* st = stage16 + cur * STAGE_ELEMS;
 #pragma unroll
       for (int kb = 0; kb < D / 16; ++kb) {
         const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&st[off]);
         const bf16x8 am = *reinterpret_cast<const bf16x8*>(&st[CT * D + off]);
+        f32x16& a = (kb & 1) ? acc2 : acc;
         if constexpr (CPIECES > 2) {
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(&st[2 * CT * D + off]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], a, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], acc, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], a, 0, 0, 0);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
       return acc;
     };
     auto offer = [&](const f32x16& acc, int64_t ct) {
@@ -648,9 +653,30 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
     };
     // Cycle stamps (-DKNN_EXP=9, tools/knn_exp.py) per wave and tile: scoring 1530 (two waves share a SIMD's matrix pipe:
     // 2 x 768), staging 660, barrier wait 1350, shortlist upkeep 1670 (queueing 980, drains 690 of which compaction 520).
-    // Negative results: letting the second wave of every SIMD do the upkeep of tile t-1 BEFORE it scores tile t (12.8 vs
-    // 12.2 ms) and parking single passes in per-lane registers until the next drain (12.5 ms) -- neither overlaps the
-    // matrix pipe with the VALU work in practice.
+    // Negative results: the skewed schedule below and parking single passes in per-lane registers until the next drain
+    // (12.5 ms).
+    // EXPERIMENT (-DKNN_SKEW, slower: 13.2 vs 11.8 ms).  Waves w and w + NW/2 share a SIMD; the second half does the
+    // upkeep of tile t-1 FIRST and scores tile t afterwards, so that in every barrier interval one wave of a SIMD feeds
+    // the matrix pipe while its partner has the VALU (bf16 MFMA and VALU do overlap across waves, fp32 MFMA does not:
+    // tools/micro/mfma_valu_overlap.hip) -- in the full kernel the upkeep's LDS traffic and scalar control flow, not
+    // VALU issue, set its length, and the skew only adds a tile of latency to the threshold updates.
+#ifdef KNN_SKEW
+    if (wave >= NW / 2) {
+      int cur = 0;
+      f32x16 accp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[r] = -INFINITY;
+      for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
+        __syncthreads();
+        if (ct + 1 < ct1) sstore(cur ^ 1);
+        if (ct + 2 < ct1) gload(ct + 2);
+        if (ct > ct0) offer(accp, ct - 1);
+        accp = score(cur);
+      }
+      offer(accp, ct1 - 1);
+    } else
+#endif
+    {
     int cur = 0;
     for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
       KSTAMP(s0);
@@ -667,6 +693,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
       offer(acc, ct);
       KSTAMP(s4);
       KACC(2, s0, s1); KACC(1, s1, s2); KACC(0, s2, s3); KACC(3, s3, s4);
+    }
     }
     emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
     t += ct1 - ct0;
