@@ -147,6 +147,7 @@ struct PullParams {
   const float* out; int64_t ldo; const float* alpha; const float* gout; int64_t ldg;
   const int32_t* t_rowptr; const int32_t* t_eid; const int32_t* t_dst;
   uint4* rec;            // [E'][2]
+  unsigned int* queue;   // [16] per-XCD dynamic tile counters (pass A: 0..7, pass B: 8..15), zeroed per call
   float* dstside;        // [N][ldh]
   float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
 };
@@ -162,7 +163,15 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
   float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;          // da partials per domain
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  __shared__ unsigned int dyn_tile;
+  const int64_t xbase = tr.begin - (blockIdx.x / 8);
+  for (;;) {
+    // per-XCD dynamic tile queue (same reason as in the forward: the blocks of an XCD stay on neighbouring rows)
+    __syncthreads();
+    if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.queue[blockIdx.x % 8], 1u);
+    __syncthreads();
+    const int64_t tile = xbase + dyn_tile;
+    if (tile >= tr.end) break;
     const int64_t i = tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.N;
     const int64_t ic = rvalid ? i : 0;
@@ -180,16 +189,28 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
     const float ti = bgnn::group_sum<LF>(gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w);
     float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accz = accd;
     const int32_t niter = (end - beg + U - 1) / U;
+    int32_t nid[U];
+    float nal[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t e = beg + u;
+      nid[u] = e < end ? p.col[e] : -1;
+      nal[u] = e < end ? p.alpha[e] : 0.f;
+    }
     for (int32_t it = 0; it < niter; ++it) {
       int32_t id[U];
       float al[U];
       float4 hj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int32_t e = beg + it * U + u;
-        id[u] = e < end ? p.col[e] : -1;
-        al[u] = e < end ? p.alpha[e] : 0.f;
+        id[u] = nid[u]; al[u] = nal[u];
         hj[u] = *reinterpret_cast<const float4*>(H + (int64_t)max(id[u], 0) * p.ldh + f0c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                 // ids / alphas of the next step fly with this step's rows
+        const int32_t e = beg + (it + 1) * U + u;
+        nid[u] = e < end ? p.col[e] : -1;
+        nal[u] = e < end ? p.alpha[e] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -248,26 +269,43 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
   }
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  __shared__ unsigned int dyn_tile;
+  const int64_t xbase = tr.begin - (blockIdx.x / 8);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.queue[8 + blockIdx.x % 8], 1u);
+    __syncthreads();
+    const int64_t tile = xbase + dyn_tile;
+    if (tile >= tr.end) break;
     const int64_t j = tile * RPB + wave * GPW + g;
     const bool rvalid = j < p.N;
     const int64_t jc = rvalid ? j : 0;
     const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
     float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
     const int32_t niter = (end - beg + U - 1) / U;
+    int32_t ne[U], ni[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t k = beg + u;
+      ne[u] = k < end ? p.t_eid[k] : -1;
+      ni[u] = k < end ? p.t_dst[k] : 0;
+    }
     for (int32_t it = 0; it < niter; ++it) {
       uint4 hd[U], mk[U];
       float4 g4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int32_t k = beg + it * U + u;
-        const bool ok = k < end;
-        const int32_t e = ok ? p.t_eid[k] : 0;
-        const int32_t i = ok ? p.t_dst[k] : 0;
-        const uint4* r = p.rec + (int64_t)e * 2;
+        const bool ok = ne[u] >= 0;
+        const uint4* r = p.rec + (int64_t)max(ne[u], 0) * 2;
         hd[u] = r[0]; mk[u] = r[1];
         if (!ok) { hd[u].x = 0u; hd[u].y = 0u; }                 // alpha = de = 0: no contribution
-        g4[u] = *reinterpret_cast<const float4*>(p.gout + (int64_t)i * p.ldg + f0c);
+        g4[u] = *reinterpret_cast<const float4*>(p.gout + (int64_t)ni[u] * p.ldg + f0c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                 // edge ids / destinations of the next step fly with this step's gathers
+        const int32_t k = beg + (it + 1) * U + u;
+        ne[u] = k < end ? p.t_eid[k] : -1;
+        ni[u] = k < end ? p.t_dst[k] : 0;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -347,7 +385,7 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_f32(const float* h_t2s, const floa
 }
 
 extern "C" size_t bgnn_aggregate_bwd_pull_workspace_bytes(int64_t N, int64_t E, int64_t ldh) {
-  return (size_t)32 * (size_t)(E > 0 ? E : 0) + sizeof(float) * (size_t)(N > 0 ? N : 0) * (size_t)(ldh > 0 ? ldh : 0) + 512;
+  return (size_t)32 * (size_t)(E > 0 ? E : 0) + sizeof(float) * (size_t)(N > 0 ? N : 0) * (size_t)(ldh > 0 ? ldh : 0) + 1024;
 }
 
 extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
@@ -370,9 +408,11 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
   if (N == 0) return 0;
   uint4* rec = (uint4*)ws;
   float* dstside = (float*)((char*)ws + bgnn_align_up((size_t)32 * (size_t)E, 256));
+  unsigned int* queue = (unsigned int*)((char*)dstside + bgnn_align_up(sizeof(float) * (size_t)N * (size_t)ldh, 256));
   PullParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, ldo, alpha, grad_out, ldg,
-               t_rowptr, t_eid, t_dst, rec, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
+               t_rowptr, t_eid, t_dst, rec, queue, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
   hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
   const int nv = (D + 3) / 4;
   return nv <= 16 ? launch_pull<16>(p, st) : launch_pull<32>(p, st);
 }
