@@ -22,6 +22,7 @@ struct GramParams {
   float* part;                  // [gridDim.x][p][q]
 };
 
+template <int PA>
 __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];     // [2][GR_RT][ldA + ldB]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -40,40 +41,47 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
   for (int t = tid; t < 2 * GR_RT * ldT; t += 256) sm[t] = 0.f;
   __syncthreads();
 
-  // staging: float4 slots of a tile = GR_RT * (nA4 + nB4), strided over the block; <= 13 per thread for p=260, q=128
+  // staging: float4 slots of a tile = GR_RT * (nA4 + nB4), strided over the block; <= 13 per thread for p=260, q=128.
+  // slot -> (row, column) is tile-invariant: the integer divisions happen once, outside the row loop (fp32 MFMA shares
+  // the VALU, so staging arithmetic competes with it directly)
   const int n4 = nA4 + nB4, nslot = GR_RT * n4;
-  constexpr int MAXS = 13;
+  constexpr int MAXS = PA == 1 ? 5 : PA <= 4 ? 8 : 13;   // (32 * (p + q) / 4) slots over 256 threads
+  int srow[MAXS], slds[MAXS], scol[MAXS];       // row inside the tile (-1: unused slot), LDS float offset, global column
+  unsigned int isA = 0;                          // bit j: slot j belongs to A
+#pragma unroll
+  for (int j = 0; j < MAXS; ++j) {
+    const int sidx = tid + 256 * j;
+    srow[j] = -1; slds[j] = 0; scol[j] = 0;
+    if (sidx < nslot) {
+      const int r = sidx / n4, c = sidx % n4;
+      srow[j] = r;
+      if (c < nA4) { isA |= 1u << j; scol[j] = c * 4; slds[j] = r * ldT + c * 4; }
+      else { scol[j] = (c - nA4) * 4; slds[j] = r * ldT + ldA + (c - nA4) * 4; }
+    }
+  }
   float4 st[MAXS];
   auto gload = [&](int t) {
 #pragma unroll
     for (int j = 0; j < MAXS; ++j) {
-      const int s = tid + 256 * j;
       st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < nslot) {
-        const int r = s / n4, c = s % n4;
-        const int64_t row = r0 + (int64_t)t * GR_RT + r;
-        if (row < r1)
-          st[j] = c < nA4 ? *reinterpret_cast<const float4*>(g.A + row * g.lda + c * 4)
-                          : *reinterpret_cast<const float4*>(g.B + row * g.ldb + (c - nA4) * 4);
+      if (srow[j] >= 0) {
+        const int64_t row = r0 + (int64_t)t * GR_RT + srow[j];
+        const bool a = (isA >> j) & 1u;
+        const float4 v = *reinterpret_cast<const float4*>((a ? g.A : g.B) + (row < r1 ? row : r1 - 1) * (a ? g.lda : g.ldb) + scol[j]);   // tail rows re-read r1-1
+        if (row < r1) st[j] = v;
       }
     }
   };
   auto sstore = [&](int buf) {
     float* base = sm + buf * GR_RT * ldT;
 #pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
-      const int s = tid + 256 * j;
-      if (s < nslot) {
-        const int r = s / n4, c = s % n4;
-        float* d = base + r * ldT + (c < nA4 ? c * 4 : ldA + (c - nA4) * 4);
-        *reinterpret_cast<float4*>(d) = st[j];
-      }
-    }
+    for (int j = 0; j < MAXS; ++j)
+      if (srow[j] >= 0) *reinterpret_cast<float4*>(base + slds[j]) = st[j];
   };
 
-  f32x16 acc[GR_PA];
+  f32x16 acc[PA];
 #pragma unroll
-  for (int a = 0; a < GR_PA; ++a)
+  for (int a = 0; a < PA; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
   const bool wave_on = wave * 32 < g.q;                  // wave-uniform
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
         const float* rowp = base + (k + fh) * ldT;
         const float b = rowp[ldA + wave * 32 + fr];
 #pragma unroll
-        for (int a = 0; a < GR_PA; ++a)
+        for (int a = 0; a < PA; ++a)
           if (a < pa) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[a * 32 + fr], b, acc[a], 0, 0, 0);
       }
     }
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
     float* out = g.part + (int64_t)blockIdx.x * g.p * g.q;
     const int col = wave * 32 + fr;
 #pragma unroll
-    for (int a = 0; a < GR_PA; ++a)
+    for (int a = 0; a < PA; ++a)
       if (a < pa) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -222,10 +230,16 @@ extern "C" int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float
   if (nblk < 1) nblk = 1;
   GramParams g{A, lda, p, B, ldb, q, N, (float*)ws};
   const size_t sh = gram_lds_bytes(p);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_partial_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-  if (attr != hipSuccess) return (int)attr;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblk), dim3(256), sh, st, g);
+  const int pa = (p + 31) / 32;
+#define BGNN_GRAM(PA)                                                                                                  \
+  do {                                                                                                                 \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_partial_kernel<PA>),         \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+    if (attr != hipSuccess) return (int)attr;                                                                          \
+    hipLaunchKernelGGL(gram_partial_kernel<PA>, dim3(nblk), dim3(256), sh, st, g);                                     \
+  } while (0)
+  if (pa <= 1) BGNN_GRAM(1); else if (pa <= 4) BGNN_GRAM(4); else BGNN_GRAM(GR_PA);
+#undef BGNN_GRAM
   BGNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((pq + 255) / 256)), dim3(256), 0, st, (const float*)ws, nblk, pq, out);
   BGNN_LAUNCH_CHECK();
