@@ -333,6 +333,133 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
   }
 }
 
+// Narrow rows (D <= 4, one float4 per row: KT-GNN's classifier convs).  Same two passes with EP lanes per row walking
+// different edges (consecutive lanes -> consecutive 16-byte records); the record is {alpha, de, domain | sign bits, -}.
+template <int EP>
+__global__ __launch_bounds__(256) void agg_bwd_dst_narrow_kernel(PullParams p) {
+  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / EP, sub = lane % EP;
+  float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const int64_t i = tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.N;
+    const int64_t ic = rvalid ? i : 0;
+    const bool dom_s = p.mask[ic] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    float4 a4;
+    a4.x = av[0]; a4.y = p.D > 1 ? av[1] : 0.f; a4.z = p.D > 2 ? av[2] : 0.f; a4.w = p.D > 3 ? av[3] : 0.f;
+    const float4 hi = *reinterpret_cast<const float4*>(H + ic * 4);
+    float4 gi = *reinterpret_cast<const float4*>(p.gout + ic * 4);
+    if (!rvalid) gi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.D < 4) gi.w = 0.f;
+    if (p.D < 3) gi.z = 0.f;
+    if (p.D < 2) gi.y = 0.f;
+    const float4 oi = *reinterpret_cast<const float4*>(p.out + ic * 4);
+    const float ti = gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w;
+    float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accz = accd;
+    for (int32_t e = beg + sub; e < end; e += EP) {
+      const int32_t j = p.col[e];
+      const float al = p.alpha[e];
+      const float4 hj = *reinterpret_cast<const float4*>(H + (int64_t)j * 4);
+      const float de = al * (gi.x * hj.x + gi.y * hj.y + gi.z * hj.z + gi.w * hj.w - ti);
+      const float zx = hj.x + hi.x, zy = hj.y + hi.y, zz = hj.z + hi.z, zw = hj.w + hi.w;
+      const bool px = zx > 0.f, py = zy > 0.f, pz = zz > 0.f, pw = zw > 0.f;
+      accd.x += de * a4.x * (px ? 1.f : p.slope); accd.y += de * a4.y * (py ? 1.f : p.slope);
+      accd.z += de * a4.z * (pz ? 1.f : p.slope); accd.w += de * a4.w * (pw ? 1.f : p.slope);
+      accz.x += de * (px ? zx : zx * p.slope); accz.y += de * (py ? zy : zy * p.slope);
+      accz.z += de * (pz ? zz : zz * p.slope); accz.w += de * (pw ? zw : zw * p.slope);
+      uint4 r;
+      r.x = __float_as_uint(al); r.y = __float_as_uint(de);
+      r.z = (dom_s ? 16u : 0u) | (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (pw ? 8u : 0u);
+      r.w = 0u;
+      p.rec[e] = r;
+    }
+#pragma unroll
+    for (int off = 1; off < EP; off <<= 1) {
+      accd.x += __shfl_xor(accd.x, off); accd.y += __shfl_xor(accd.y, off); accd.z += __shfl_xor(accd.z, off); accd.w += __shfl_xor(accd.w, off);
+    }
+    if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.dstside + i * 4) = accd;
+    if (rvalid) {
+      if (dom_s) { accS.x += accz.x; accS.y += accz.y; accS.z += accz.z; accS.w += accz.w; }
+      else       { accT.x += accz.x; accT.y += accz.y; accT.z += accz.z; accT.w += accz.w; }
+    }
+  }
+  // da: wave reduction, then one atomic per (wave, column, domain)
+  float v[8] = {accS.x, accS.y, accS.z, accS.w, accT.x, accT.y, accT.z, accT.w};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v[c] = bgnn::group_sum<64>(v[c]);
+    if (lane == 0 && (c & 3) < p.D) unsafeAtomicAdd(c < 4 ? &p.da_t2s[c] : &p.da_s2t[c - 4], v[c]);
+  }
+}
+
+template <int EP>
+__global__ __launch_bounds__(256) void agg_bwd_src_narrow_kernel(PullParams p) {
+  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / EP, sub = lane % EP;
+  float4 aS, aT;
+  aS.x = p.a_t2s[0]; aS.y = p.D > 1 ? p.a_t2s[1] : 0.f; aS.z = p.D > 2 ? p.a_t2s[2] : 0.f; aS.w = p.D > 3 ? p.a_t2s[3] : 0.f;
+  aT.x = p.a_s2t[0]; aT.y = p.D > 1 ? p.a_s2t[1] : 0.f; aT.z = p.D > 2 ? p.a_s2t[2] : 0.f; aT.w = p.D > 3 ? p.a_s2t[3] : 0.f;
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const int64_t j = tile * RPB + wave * GPW + g;
+    const bool rvalid = j < p.N;
+    const int64_t jc = rvalid ? j : 0;
+    const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
+    float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
+    for (int32_t k = beg + sub; k < end; k += EP) {
+      const int32_t e = p.t_eid[k], i = p.t_dst[k];
+      const uint4 r = p.rec[e];
+      float4 g4 = *reinterpret_cast<const float4*>(p.gout + (int64_t)i * 4);
+      if (p.D < 4) g4.w = 0.f;
+      if (p.D < 3) g4.z = 0.f;
+      if (p.D < 2) g4.y = 0.f;
+      const float al = __uint_as_float(r.x), de = __uint_as_float(r.y);
+      const bool ds = (r.z & 16u) != 0u;
+      const float4 a4 = ds ? aS : aT;
+      float4 v;
+      v.x = fmaf(al, g4.x, de * a4.x * ((r.z & 1u) ? 1.f : p.slope));
+      v.y = fmaf(al, g4.y, de * a4.y * ((r.z & 2u) ? 1.f : p.slope));
+      v.z = fmaf(al, g4.z, de * a4.z * ((r.z & 4u) ? 1.f : p.slope));
+      v.w = fmaf(al, g4.w, de * a4.w * ((r.z & 8u) ? 1.f : p.slope));
+      if (ds) { accS.x += v.x; accS.y += v.y; accS.z += v.z; accS.w += v.w; }
+      else    { accT.x += v.x; accT.y += v.y; accT.z += v.z; accT.w += v.w; }
+    }
+#pragma unroll
+    for (int off = 1; off < EP; off <<= 1) {
+      accS.x += __shfl_xor(accS.x, off); accS.y += __shfl_xor(accS.y, off); accS.z += __shfl_xor(accS.z, off); accS.w += __shfl_xor(accS.w, off);
+      accT.x += __shfl_xor(accT.x, off); accT.y += __shfl_xor(accT.y, off); accT.z += __shfl_xor(accT.z, off); accT.w += __shfl_xor(accT.w, off);
+    }
+    if (rvalid && sub == 0) {
+      const bool dom_j = p.mask[j] != 0;
+      const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * 4);
+      if (dom_j) { accS.x += ds4.x; accS.y += ds4.y; accS.z += ds4.z; accS.w += ds4.w; }
+      else       { accT.x += ds4.x; accT.y += ds4.y; accT.z += ds4.z; accT.w += ds4.w; }
+      *reinterpret_cast<float4*>(p.dh_t2s + j * 4) = accS;
+      *reinterpret_cast<float4*>(p.dh_s2t + j * 4) = accT;
+    }
+  }
+}
+
+static int launch_pull_narrow(const PullParams& p, hipStream_t st) {
+  constexpr int EP = 8, RPB = 4 * (64 / EP);
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_bwd_dst_narrow_kernel<EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL((agg_bwd_src_narrow_kernel<EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int LF>
 int launch_pull(const PullParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / LF);
@@ -400,7 +527,8 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_eid || !t_dst || !out || !alpha ||
       !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
     return BGNN_E_NULL;
-  if (N < 0 || E < 0 || D <= 32 || D > 128 || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
+  const bool narrow = D >= 1 && D <= 4 && ldh == 4 && ldo == 4 && ldg == 4;
+  if (N < 0 || E < 0 || (!narrow && (D <= 32 || D > 128)) || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
       !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
     return BGNN_E_ALIGN;
@@ -413,6 +541,7 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
                t_rowptr, t_eid, t_dst, rec, queue, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (narrow) return launch_pull_narrow(p, st);
   const int nv = (D + 3) / 4;
   return nv <= 16 ? launch_pull<16>(p, st) : launch_pull<32>(p, st);
 }
