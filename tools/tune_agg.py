@@ -23,6 +23,7 @@ dev = "cuda:0"
 def run(graph, D, variants, n=1_000_000):
     ns = n // 2
     ei, mask = synth.bridged_graph(ns, n - ns, 6, 20, 4_000_000, p_local=0.9 if graph == "local" else 0.0, seed=0)
+    print('edges', ei.shape, flush=True)
     csr = ops.build_dst_csr(torch.from_numpy(ei).to(dev), n)
     ld = ops.pad4(D)
     hS = torch.zeros(n, ld, device=dev); hT = torch.zeros(n, ld, device=dev)
@@ -59,7 +60,12 @@ def run(graph, D, variants, n=1_000_000):
 
 if __name__ == "__main__":
     allres = {}
-    if os.environ.get("TUNE_QUICK"):
+    if os.environ.get("TUNE_SMALL"):
+        # L2-resident tables: is the kernel or the memory system the bound?
+        for n in (4096, 32768, 262144):
+            allres[f"local_D128_n{n}"] = run("local", 128, [0, 40, 41], n=n)
+            allres[f"uniform_D128_n{n}"] = run("uniform", 128, [40], n=n)
+    elif os.environ.get("TUNE_QUICK"):
         allres["local_D128"] = run("local", 128, [0, 40, 41])
         allres["uniform_D128"] = run("uniform", 128, [0, 40, 41])
         allres["local_D64"] = run("local", 64, [23, 42, 43])
