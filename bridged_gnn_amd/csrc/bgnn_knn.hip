@@ -659,7 +659,9 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
     // upkeep of tile t-1 FIRST and scores tile t afterwards, so that in every barrier interval one wave of a SIMD feeds
     // the matrix pipe while its partner has the VALU (bf16 MFMA and VALU do overlap across waves, fp32 MFMA does not:
     // tools/micro/mfma_valu_overlap.hip) -- in the full kernel the upkeep's LDS traffic and scalar control flow, not
-    // VALU issue, set its length, and the skew only adds a tile of latency to the threshold updates.
+    // VALU issue, set its length, and the skew only adds a tile of latency to the threshold updates.  (Skewing only the
+    // staging -- second wave scores first, stages afterwards -- is equally flat: 12.4 vs 11.7 ms.  Waves w and w+4 do share
+    // a SIMD: tools/micro/wave_simd_map.hip.)
 #ifdef KNN_SKEW
     if (wave >= NW / 2) {
       int cur = 0;
