@@ -140,6 +140,35 @@ def test_linear_relu_colsum(din, dout, n, relu):
     assert torch.equal(ops.linear(_t(x), _t(W), _t(b), relu=relu), out)      # sums are optional
 
 
+def test_graph_replay_matches_eager():
+    """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
+    order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    n, feat, hidden, C = 5000, 32, 64, 3
+    ei, mask = synth.random_multigraph(n, 40000, frac_src=0.5, seed=5)
+    torch.manual_seed(0)
+    model = KTGNN_no_complement(feat, C, 2, hidden, use_bn=True, dim_share=feat).to(DEV).eval()
+    x = torch.randn(n, feat, device=DEV)
+    data = Data(x=x, edge_index=_t(ei), central_mask=_t(mask))
+    with torch.no_grad():
+        eager = [t.clone() for t in model(data)[:3]]
+    run = model.graphed(data)
+    rep = run()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, rep[:3]):
+        assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="replay")
+    x.mul_(0.5)                                   # in-place change of the captured input
+    with torch.no_grad():
+        eager2 = [t.clone() for t in model(data)[:3]]
+    rep2 = run()
+    torch.cuda.synchronize()
+    for a, b in zip(eager2, rep2[:3]):
+        assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="replay after x update")
+    assert float((eager[0] - eager2[0]).abs().max()) > 1e-3
+
+
 def test_root_weight_and_normalize_paths():
     from bridged_gnn_amd import ops, synth
     from bridged_gnn_amd.ktgnn import AdaptedConv
