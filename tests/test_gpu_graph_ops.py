@@ -1,4 +1,6 @@
 """GPU: integer edge-list plumbing through the C ABI, bit-exact vs the oracle / golden vectors."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -96,3 +98,38 @@ def test_cpu_tensors_are_refused():
         ops.build_dst_csr(torch.zeros(2, 3, dtype=torch.int64), 4)
     with pytest.raises(RuntimeError):
         utils.coalesce(torch.zeros(2, 3, dtype=torch.int64))
+
+
+def test_training_entry_points_reject_shapes_outside_their_envelope():
+    """argument validation of the dense-side entry points (no kernel runs): the callers rely on these codes to fall
+    back to a library GEMM outside the kernels' envelopes."""
+    from bridged_gnn_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, 128, device=DEV)
+    w = torch.zeros(96, 128, device=DEV)
+    b = torch.zeros(96, device=DEV)
+    o = torch.zeros(64, 96, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    # Dout % 64 != 0
+    assert L.bgnn_linear_f32(p(x), 64, 128, 128, p(w), p(b), 96, 0, None, None, p(o), 96, None) == -2
+    # Din > 128
+    assert L.bgnn_linear_f32(p(x), 64, 256, 256, p(w), p(b), 64, 0, None, None, p(o), 64, None) == -2
+    # column sums without a mask
+    s = torch.zeros(130, dtype=torch.float64, device=DEV)
+    assert L.bgnn_linear_f32(p(x), 64, 128, 128, p(w), p(b), 64, 0, None, p(s), p(o), 64, None) == -1
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    # gram: p > 288, q > 128, q % 4 != 0, workspace too small
+    assert L.bgnn_gram_f32(p(x), 128, 292, p(x), 128, 128, 64, p(o), p(ws), ws.numel(), None) == -2
+    assert L.bgnn_gram_f32(p(x), 128, 128, p(x), 128, 132, 64, p(o), p(ws), ws.numel(), None) == -2
+    assert L.bgnn_gram_f32(p(x), 128, 128, p(x), 128, 6, 64, p(o), p(ws), ws.numel(), None) == -2
+    assert L.bgnn_gram_f32(p(x), 128, 128, p(x), 128, 128, 64, p(o), p(ws), 16, None) == -3
+    # rowdot: more than four vectors, d > 256
+    assert L.bgnn_rowdot_f32(p(x), 128, 64, 128, p(w), 128, 5, p(o), None) == -2
+    assert L.bgnn_rowdot_f32(p(x), 128, 64, 260, p(w), 260, 1, p(o), None) == -2
+    # pull backward: 4 < D <= 32 has no pull form
+    i32 = torch.zeros(8, dtype=torch.int32, device=DEV)
+    m = torch.zeros(8, dtype=torch.uint8, device=DEV)
+    rc = L.bgnn_adaptedconv_aggregate_bwd_pull_f32(p(x), p(x), 16, p(b), p(b), p(i32), p(i32), p(m), p(i32), p(i32), p(i32), 4, 0, 16, 0.1,
+                                                   p(x), 16, p(b), p(x), 16, p(o), p(o), p(b), p(b), p(ws), ws.numel(), None)
+    assert rc == -2
+
