@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--knn-n", type=int, default=100_000)
     ap.add_argument("--train-steps", type=int, default=0, help="also time this many training steps (fwd+bwd+Adam, reference loss)")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned (RCCL) code path even at world size 1")
+    ap.add_argument("--graph-replay", action="store_true",
+                    help="after the timed (eager) loop, also capture the forward into a HIP graph and report its replay time "
+                         "as `graph_replay_ms_per_step` (opt-in: capturing RCCL collectives is validated at world size 1 only)")
     return ap.parse_args()
 
 
@@ -263,6 +266,29 @@ def main():
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
     agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
 
+    graph_ms = None
+    if args.graph_replay:
+        try:
+            with torch.no_grad():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    runner()
+                for _ in range(3):
+                    g.replay()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    g.replay()
+                barrier()
+                gdt = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([gdt], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                gdt = float(tt.item())
+            graph_ms = gdt / args.steps * 1e3
+        except Exception as exc:                      # capture is an extra, never the measurement
+            graph_ms = f"capture failed: {type(exc).__name__}"
+
     train = None
     if args.train_steps > 0 and not use_dist:
         # one optimisation step = train-mode forward (dropout, batch-stat BN) + HIP backward + Adam
@@ -309,6 +335,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args, world), "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
         }
+        if graph_ms is not None:
+            out["graph_replay_ms_per_step"] = graph_ms
         if knn is not None:
             out["knn"] = knn
         if train is not None:
