@@ -185,7 +185,7 @@ _TILE_QUEUES = {}
 
 def _tile_queue(dev):
     """8 x uint32 scratch per (device, stream) for the aggregation kernel's per-XCD dynamic tile counters."""
-    key = (torch.device(dev).index, torch.cuda.current_stream().cuda_stream)
+    key = (torch.device(dev).index, L.raw_stream())
     q = _TILE_QUEUES.get(key)
     if q is None:
         q = _TILE_QUEUES[key] = torch.zeros(8, dtype=torch.int32, device=dev)
