@@ -140,6 +140,66 @@ def test_linear_relu_colsum(din, dout, n, relu):
     assert torch.equal(ops.linear(_t(x), _t(W), _t(b), relu=relu), out)      # sums are optional
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_aggregate_fuzz_vs_c_oracle(seed):
+    """seeded random shapes through the aggregation dispatch (narrow / wide / pad lanes / epilogue / column sums):
+    D, slope, degree mix (isolated rows, a hub), domain split."""
+    from bridged_gnn_amd import ops, synth
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([1, 3, 4, 6, 12, 20, 33, 36, 48, 64, 72, 100, 128, 132, 200, 256]))
+    n = int(rng.integers(50, 3000))
+    ei, mask = synth.random_multigraph(n, int(rng.integers(1, 12)) * n, frac_src=float(rng.uniform(0.1, 0.9)),
+                                       n_isolated=int(rng.integers(0, 5)), seed=seed)
+    hub = np.stack([rng.integers(0, n, 3000), np.full(3000, int(rng.integers(0, n)))])
+    ei = np.concatenate([ei, hub], axis=1).astype(np.int64)
+    slope = float(rng.choice([0.0, 0.1, 0.2, 1.0]))
+    hS = rng.standard_normal((n, D)).astype(np.float32)
+    hT = rng.standard_normal((n, D)).astype(np.float32)
+    a1, a2 = (rng.standard_normal(D) * 0.3).astype(np.float32), (rng.standard_normal(D) * 0.3).astype(np.float32)
+    csr = ops.build_dst_csr(_t(ei), n)
+    ld = ops.pad4(D)
+    tS = torch.zeros(n, ld, device=DEV); tT = torch.zeros(n, ld, device=DEV)
+    tS[:, :D], tT[:, :D] = _t(hS), _t(hT)
+    m8 = _t(mask).to(torch.uint8)
+    sums = torch.zeros(2 * ld + 2, dtype=torch.float64, device=DEV)
+    sc = _t(rng.uniform(0.5, 1.5, D).astype(np.float32)); sh = _t(rng.standard_normal(D).astype(np.float32))
+    out = ops.adaptedconv_aggregate(tS, tT, _t(a1), _t(a2), csr, m8, D, slope, ep_scale=sc, ep_shift=sh, ep_relu=True, colsum=sums)
+    rowptr, col, _ = O.dst_csr(ei, mask)
+    ref = OC.adaptedconv_aggregate(hS, hT, a1, a2, rowptr, col, mask, slope=slope)
+    ref = np.maximum(ref * sc.cpu().numpy() + sh.cpu().numpy(), 0.0)
+    got = out[:, :D].cpu().numpy()
+    assert_close(got, ref, rtol=2e-5, atol_scale=4e-6, what=f"fuzz seed={seed} D={D} n={n} slope={slope}")
+    s = sums.cpu().numpy()
+    np.testing.assert_allclose(s[:D], got[mask].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[ld:ld + D], got[~mask].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    assert s[2 * ld] == mask.sum() and s[2 * ld + 1] == (~mask).sum()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_transform_fuzz_vs_c_oracle(seed):
+    """seeded random (Din, D, N) through the transform dispatch (W-stationary fp32 / bf16x3, skinny, tiled GEMM)."""
+    from bridged_gnn_amd.ktgnn import AdaptedConv, _as_u8
+    rng = np.random.default_rng(7000 + seed)
+    din = int(rng.choice([4, 8, 20, 32, 36, 64, 100, 128, 132, 200, 300]))
+    D = int(rng.choice([1, 2, 5, 10, 12, 16, 32, 40, 64, 96, 100, 128, 192, 256]))
+    n = int(rng.integers(1, 5000))
+    mask = rng.random(n) < rng.uniform(0.2, 0.8)
+    if mask.all() or not mask.any():
+        mask[0], mask[-1] = True, False
+    if n == 1:
+        pytest.skip("a single row cannot hold both domains")
+    x = (rng.standard_normal((n, din)) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+    torch.manual_seed(seed)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV).eval()
+    with torch.no_grad():
+        h_t2s, h_s2t = conv.transform(_t(x), _as_u8(_t(mask)))
+    prm = {k: v.cpu().numpy() for k, v in conv.state_dict().items()}
+    hs2t, ht2s = OC.adaptedconv_transform(x, mask, prm)
+    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=2e-6, what=f"h_t2s seed={seed} din={din} D={D} n={n}")
+    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=2e-6, what=f"h_s2t seed={seed} din={din} D={D} n={n}")
+    assert float(h_t2s[:, D:].abs().max()) == 0.0 if h_t2s.shape[1] > D else True     # pad columns stay exactly zero
+
+
 def test_graph_replay_matches_eager():
     """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
     order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""

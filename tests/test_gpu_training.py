@@ -69,6 +69,36 @@ def test_rowdot_kernel_vs_fp64(d, nv, n):
     assert _rel(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_pull_backward_equals_atomic_backward(seed):
+    """the atomic-free pull form and the atomic scatter form of the aggregation backward are the same function: compare
+    them against each other on seeded random shapes inside the pull envelope (D <= 4 and 32 < D <= 128)."""
+    from bridged_gnn_amd import _lib, ops, synth
+    rng = np.random.default_rng(300 + seed)
+    D = int(rng.choice([1, 2, 3, 4, 36, 40, 64, 100, 128]))
+    n = int(rng.integers(40, 2500))
+    ei, mask = synth.random_multigraph(n, int(rng.integers(1, 10)) * n, frac_src=float(rng.uniform(0.2, 0.8)), n_isolated=2, seed=seed)
+    csr = ops.build_dst_csr(_t(ei), n)
+    ld = ops.pad4(D)
+    hS = torch.zeros(n, ld, device=DEV); hT = torch.zeros(n, ld, device=DEV)
+    hS[:, :D] = torch.randn(n, D, device=DEV); hT[:, :D] = torch.randn(n, D, device=DEV)
+    a1, a2 = torch.randn(D, device=DEV) * 0.3, torch.randn(D, device=DEV) * 0.3
+    m8 = _t(mask).to(torch.uint8)
+    out, alpha = ops.adaptedconv_aggregate(hS, hT, a1, a2, csr, m8, D, 0.1, want_alpha=True)
+    g = torch.zeros(n, ld, device=DEV); g[:, :D] = torch.randn(n, D, device=DEV)
+    pull = ops.adaptedconv_aggregate_bwd(hS, hT, a1, a2, csr, m8, D, out, alpha, g, 0.1)
+    # the atomic form, called directly
+    L = _lib.lib()
+    d1, d2 = torch.zeros_like(hS), torch.zeros_like(hT)
+    da1, da2 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    rc = L.bgnn_adaptedconv_aggregate_bwd_f32(_lib.ptr(hS), _lib.ptr(hT), ld, _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
+                                              _lib.ptr(m8), 0, n, D, 0.1, _lib.ptr(out), ld, _lib.ptr(alpha), _lib.ptr(g), ld,
+                                              _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(da1), _lib.ptr(da2), _lib.stream())
+    assert rc == 0
+    for name, a, b in (("dh_t2s", pull[0], d1), ("dh_s2t", pull[1], d2), ("da_t2s", pull[2], da1), ("da_s2t", pull[3], da2)):
+        assert _rel(a.double().cpu(), b.double().cpu()) < 2e-5, (name, D, n)
+
+
 def test_training_steps_follow_the_autograd_oracle():
     """3 Adam steps of the reference recipe (lr 1e-3, wd 5e-3, loss of main_graph_knowledge_transfer.py:44-54),
     dropout off, BN in train mode: loss trajectory and final weights vs the CPU torch oracle model."""
