@@ -39,6 +39,29 @@ def test_cosine_topk_bit_exact(nq, nc, d, k):
     assert int(nfb.item()) <= max(2, nq // 100)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_cosine_topk_fuzz_bit_exact(seed):
+    """seeded random (Nq, Nc, d, k), clustered embeddings with near-duplicates: indices bit-exact vs the C oracle through
+    the bf16-piece pass 1 + canonical re-score (+ exhaustive fallback when the proof margin is too small)."""
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(500 + seed)
+    d = int(rng.choice([32, 64, 128, 128, 256]))
+    k = int(rng.choice([1, 3, 8, 20, 24])) if d == 256 else int(rng.choice([1, 3, 8, 20, 24, 30, 50]))
+    nq, nc = int(rng.integers(1, 700)), int(rng.integers(max(k, 33), 12000))
+    centers = rng.standard_normal((8, d))
+    def emb(n):
+        z = centers[rng.integers(0, 8, n)] + rng.standard_normal((n, d)) * rng.choice([0.05, 0.3, 1.0])
+        return z.astype(np.float32)
+    qe, ce = emb(nq), emb(nc)
+    ce[rng.integers(0, nc, 5)] = ce[rng.integers(0, nc, 5)]              # exact duplicates
+    ce[rng.integers(0, nc, 5)] *= np.float32(1.0 + 1e-6)                  # near duplicates (same direction up to rounding)
+    q, c = OC.l2_normalize_rows(qe), OC.l2_normalize_rows(ce)
+    idx, val, nfb = ops.cosine_topk(_t(q), _t(c), k, apply_sigmoid=False)
+    rv, ri = OC.cosine_topk(q, c, k)
+    assert np.array_equal(idx.cpu().numpy(), ri), f"seed={seed} d={d} k={k} nq={nq} nc={nc} fallback={int(nfb.item())}"
+    assert_close(val.cpu().numpy(), rv, rtol=1e-6, atol_scale=1e-7, what="scores")
+
+
 def test_cosine_topk_exact_ties_and_duplicates():
     """duplicated candidates give exactly equal scores: the lower index must win, everywhere."""
     from bridged_gnn_amd import ops, synth
