@@ -38,7 +38,8 @@ struct AggParams {
   int ep_relu;
   unsigned int* tile_queue;   // optional [8], zeroed per launch: per-XCD dynamic tile counters.  Static striding lets the
                      // blocks of an XCD drift apart (the set of rows in flight outgrows the 4 MB L2); pulling the next
-                     // tile from a shared counter keeps them on neighbouring rows (-7 % on the bridged graph)
+                     // CHUNK of 4 tiles from a shared counter keeps them on neighbouring rows (HBM traffic 7.3 -> 2.4 GB;
+                     // one atomic per tile was itself the bound: same-address device atomics retire at ~11 M/s)
   double* colsum;    // optional [2*ldo + 2]: per-domain column sums (+ node counts) of the finished output rows, i.e. the
                      // domain sums the NEXT conv needs (KTGNN.py:275) without another pass over the activations
   int32_t heads;     // H convs evaluated together: tables/out are [N, H*ldh'] interleaved, a_* are [H][D]; a (row, head)
@@ -75,12 +76,20 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   __shared__ unsigned int dyn_tile;
   const int64_t xbase = tr.begin - (blockIdx.x / 8);        // first tile of this XCD's range
   int64_t tile = tr.begin - tr.step;
+  int64_t chunk_left = 0;
+  constexpr int TQ_CHUNK = 4;                               // tiles per queue fetch (see agg_wide_kernel)
   for (;;) {
     if (p.tile_queue != nullptr) {                          // kernel-uniform
-      __syncthreads();
-      if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
-      __syncthreads();
-      tile = xbase + dyn_tile;
+      if (chunk_left == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
+        __syncthreads();
+        tile = xbase + (int64_t)dyn_tile * TQ_CHUNK;
+        chunk_left = TQ_CHUNK;
+      } else {
+        tile += 1;
+      }
+      --chunk_left;
     } else {
       tile += tr.step;
     }
@@ -296,13 +305,27 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   const f2 sl = {p.slope, p.slope};
   float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // column sums of the rows this lane wrote, per domain
   float n_s = 0.f, n_t = 0.f;
+  // The queue hands out CHUNKS of TQ_CHUNK consecutive tiles: device-scope atomics on ONE address retire at only
+  // ~11 M/s (90 ns each, measured), so one atomic per 8-row tile put a floor of 125k tiles x 90 ns / 8 queues = 1.4 ms
+  // under the C4 launch -- the kernel took 1.45 ms for 1 to 42 in-edges per row alike.
+#ifndef AGG_TQ_CHUNK
+#define AGG_TQ_CHUNK 4
+#endif
+  constexpr int TQ_CHUNK = AGG_TQ_CHUNK;
   int64_t tile = tr.begin - tr.step;
+  int64_t chunk_left = 0;
   for (;;) {
     if (p.tile_queue != nullptr) {
-      __syncthreads();
-      if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
-      __syncthreads();
-      tile = xbase + dyn_tile;
+      if (chunk_left == 0) {                     // block-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
+        __syncthreads();
+        tile = xbase + (int64_t)dyn_tile * TQ_CHUNK;
+        chunk_left = TQ_CHUNK;
+      } else {
+        tile += 1;
+      }
+      --chunk_left;
     } else {
       tile += tr.step;
     }

@@ -60,7 +60,10 @@ def run(graph, D, variants, n=1_000_000):
 
 if __name__ == "__main__":
     allres = {}
-    if os.environ.get("TUNE_SMALL"):
+    if os.environ.get("TUNE_C4ONLY"):
+        allres["local_D128"] = run("local", 128, [40, 41])
+        allres["uniform_D128"] = run("uniform", 128, [40, 41])
+    elif os.environ.get("TUNE_SMALL"):
         # L2-resident tables: is the kernel or the memory system the bound?
         for n in (4096, 32768, 262144):
             allres[f"local_D128_n{n}"] = run("local", 128, [0, 40, 41], n=n)
