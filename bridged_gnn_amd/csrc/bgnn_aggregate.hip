@@ -303,6 +303,13 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   const int64_t xbase = tr.begin - (blockIdx.x / 8);
   const uint32_t nstride = (uint32_t)(p.heads * p.ldh * 4);   // bytes between neighbour rows of one head (host-checked < 2^32)
   const f2 sl = {p.slope, p.slope};
+  // epilogue affine of this lane's four columns: loaded once (eight dependent loads per ROW sat on every row's critical path)
+  float sc4[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.ep_scale != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (f0 + c < p.D) { sc4[c] = p.ep_scale[f0 + c]; sh4[c] = p.ep_shift[f0 + c]; }
+  }
   float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // column sums of the rows this lane wrote, per domain
   float n_s = 0.f, n_t = 0.f;
   // The queue hands out CHUNKS of TQ_CHUNK consecutive tiles: device-scope atomics on ONE address retire at only
@@ -477,13 +484,6 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
     if (rvalid && f0 < p.ldo) {
       float4 o = make_float4(acc01.x * inv, acc01.y * inv, acc23.x * inv, acc23.y * inv);
       if (p.ep_scale != nullptr) {
-        float sc4[4], sh4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bool ok = f0 + c < p.D;
-          sc4[c] = ok ? p.ep_scale[f0 + c] : 0.f;
-          sh4[c] = ok ? p.ep_shift[f0 + c] : 0.f;
-        }
         o.x = fmaf(o.x, sc4[0], sh4[0]); o.y = fmaf(o.y, sc4[1], sh4[1]);
         o.z = fmaf(o.z, sc4[2], sh4[2]); o.w = fmaf(o.w, sc4[3], sh4[3]);
       }
