@@ -62,9 +62,13 @@ def parse():
     ap.add_argument("--knn-n", type=int, default=100_000)
     ap.add_argument("--train-steps", type=int, default=0, help="also time this many training steps (fwd+bwd+Adam, reference loss)")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned (RCCL) code path even at world size 1")
-    ap.add_argument("--graph-replay", action="store_true",
-                    help="after the timed (eager) loop, also capture the forward into a HIP graph and report its replay time "
-                         "as `graph_replay_ms_per_step` (opt-in: capturing RCCL collectives is validated at world size 1 only)")
+    ap.add_argument("--graph-replay", action="store_true", help="(default behaviour now; kept for old command lines)")
+    ap.add_argument("--no-graph-replay", action="store_true",
+                    help="skip the HIP-graph phase: by default the forward (collectives included) is captured once after the "
+                         "eager measurement, checked against the eager outputs and timed for the same K steps; the faster "
+                         "of the two is `value`, both are reported")
+    ap.add_argument("--graph-timeout", type=float, default=60.0,
+                    help="seconds the HIP-graph phase may take before the eager result is printed and the process exits")
     return ap.parse_args()
 
 
@@ -175,6 +179,63 @@ def knn_bench(args, dev, rank=0, world=1):
             "mfma_fp32_frac": (pairs * 256 / t) / (157.3e12 * world)}
 
 
+def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
+    """Capture ONE forward (every launch of it, and at N>1 its RCCL collectives) into a HIP graph, check the replayed
+    outputs against an eager forward on every rank, time the same K steps as replays.  `out` (rank 0's result line,
+    already complete from the eager measurement) is switched to the replay numbers only when every rank verified its
+    outputs and the replay is faster.  A watchdog prints the eager line and ends the process if the phase stalls (a
+    graph-launched collective is the one thing here that cannot be rehearsed on a one-GPU box)."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.graph_timeout):
+            if rank == 0:
+                out["graph_replay_ms_per_step"] = f"stalled (> {args.graph_timeout:.0f} s), eager result kept"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    note = None
+    try:
+        with torch.no_grad():
+            ref = [t.clone() for t in runner()[:3]]
+            barrier()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                got = runner()[:3]
+            for _ in range(3):
+                g.replay()
+            barrier()
+            ok = all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(got, ref))
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            barrier()
+            gdt = time.perf_counter() - t0
+        res = torch.tensor([gdt, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
+        if use_dist:
+            torch.distributed.all_reduce(res, op=torch.distributed.ReduceOp.MAX)
+        gdt, bad = float(res[0].item()), float(res[1].item())
+        graph_ms = gdt / args.steps * 1e3
+        if bad:
+            note = "replayed outputs differ from the eager outputs, eager result kept"
+    except Exception as exc:                              # the eager measurement stands
+        note = f"capture failed: {type(exc).__name__}: {str(exc)[:120]}"
+    done.set()
+    if out is None:
+        return
+    if note is not None:
+        out["graph_replay_ms_per_step"] = note
+        return
+    out["graph_replay_ms_per_step"] = graph_ms
+    if graph_ms < out["ms_per_step"]:
+        out["ms_per_step"] = graph_ms
+        out["value"] = units / (graph_ms * 1e-3)
+        out["config"]["execution"] = ("HIP-graph replay: the whole forward (all launches" +
+                                      (" and the RCCL collectives" if use_dist else "") +
+                                      ") captured once, outputs checked against the eager forward, K replays timed")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -266,29 +327,6 @@ def main():
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
     agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
 
-    graph_ms = None
-    if args.graph_replay:
-        try:
-            with torch.no_grad():
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    runner()
-                for _ in range(3):
-                    g.replay()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    g.replay()
-                barrier()
-                gdt = time.perf_counter() - t0
-            if use_dist:
-                tt = torch.tensor([gdt], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-                gdt = float(tt.item())
-            graph_ms = gdt / args.steps * 1e3
-        except Exception as exc:                      # capture is an extra, never the measurement
-            graph_ms = f"capture failed: {type(exc).__name__}"
-
     train = None
     if args.train_steps > 0 and not use_dist:
         # one optimisation step = train-mode forward (dropout, batch-stat BN) + HIP backward + Adam
@@ -318,6 +356,7 @@ def main():
                  "what": "train-mode forward + backward (HIP kernels: pull + atomic aggregation backward, Gram/row-dot transform backward) + Adam on C4"}
         model.eval()
     knn = knn_bench(args, dev, rank, world) if not args.no_knn else None     # every rank takes part when N > 1
+    out = None
     if rank == 0:
         n_local = N if not use_dist else len(pk.owned_global)
         e_local = Eprime if not use_dist else pk.local_num_edges
@@ -335,14 +374,17 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args, world), "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
         }
-        if graph_ms is not None:
-            out["graph_replay_ms_per_step"] = graph_ms
         if knn is not None:
             out["knn"] = knn
         if train is not None:
             out["train"] = train
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
+        out["eager_ms_per_step"] = ms_step
+        out["config"]["execution"] = "eager launches"
+    if not args.no_graph_replay:
+        graph_phase(args, runner, barrier, use_dist, dev, rank, out, 4 * Eprime)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.barrier()

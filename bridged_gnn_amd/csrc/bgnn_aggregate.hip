@@ -615,7 +615,23 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
           *reinterpret_cast<float4*>(o) = acc[h];
         } else {
           const float inv = 1.f / (s[h] + 1e-16f);
-          *reinterpret_cast<float4*>(o) = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+          float4 r = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+          if (p.ep_relu == 2) {    // log_softmax over the head's D classes (KTGNN.py:435), row-local
+            float mx = r.x;
+            if (p.D > 1) mx = fmaxf(mx, r.y);
+            if (p.D > 2) mx = fmaxf(mx, r.z);
+            if (p.D > 3) mx = fmaxf(mx, r.w);
+            float se = expf(r.x - mx);
+            if (p.D > 1) se += expf(r.y - mx);
+            if (p.D > 2) se += expf(r.z - mx);
+            if (p.D > 3) se += expf(r.w - mx);
+            const float lse = logf(se);
+            r.x = r.x - mx - lse;
+            r.y = p.D > 1 ? r.y - mx - lse : 0.f;
+            r.z = p.D > 2 ? r.z - mx - lse : 0.f;
+            r.w = p.D > 3 ? r.w - mx - lse : 0.f;
+          }
+          *reinterpret_cast<float4*>(o) = r;
         }
       }
     }
@@ -702,6 +718,9 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if (colsum_opt && (heads != 1 || part == 1)) return BGNN_E_SHAPE;
   if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
   if (heads < 1 || heads > 8 || (heads > 1 && (alpha_opt || ep_scale_opt))) return BGNN_E_SHAPE;
+  if (ep_relu < 0 || ep_relu > 2) return BGNN_E_SHAPE;
+  // ep_relu == 2: log_softmax epilogue instead of ReLU -- only the interleaved narrow-heads kernel has it
+  if (ep_relu == 2 && !((heads == 3 || heads == 2) && D <= 4 && ldh == 4 && ldo == 4)) return BGNN_E_SHAPE;
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
   if (row_begin < 0 || row_end < row_begin || D <= 0 || D > 256 || ldh < D || ldo < D) return BGNN_E_SHAPE;
   if ((ldh & 3) || (ldo & 3) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out))

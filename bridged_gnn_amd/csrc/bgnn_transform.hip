@@ -104,16 +104,23 @@ __global__ void domain_delta_kernel(const double* __restrict__ sums, int32_t Din
 
 // ------------------------------------------------------------------ W.delta and gate constants
 // wd[j] = Wp[j] . delta (j < NC) ; gc[h*2+t] = g[h][t][Din:] . delta
+// delta comes either as a vector or, with `sums` (the [2*Din+2] domain sums), is formed on the fly with the arithmetic
+// of domain_delta_kernel (one launch less per conv; bit-identical)
 __global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, int32_t NC, int32_t Din,
-                                                 const float* __restrict__ delta, const float* __restrict__ g,
-                                                 const float* __restrict__ gate_const,
+                                                 const float* __restrict__ delta, const double* __restrict__ sums,
+                                                 const float* __restrict__ g, const float* __restrict__ gate_const,
                                                  int32_t n_heads, float* __restrict__ wd, float* __restrict__ gc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = NC + 2 * n_heads;
+  double ns = 1.0, nt = 1.0;
+  if (sums) { ns = sums[2 * Din]; nt = sums[2 * Din + 1]; }
   for (int j = blockIdx.x * 4 + wave; j < nrows; j += gridDim.x * 4) {
     const float* row = j < NC ? Wp + (int64_t)j * Din : g + (int64_t)(j - NC) * 2 * Din + Din;
     float acc = 0.f;
-    for (int c = lane; c < Din; c += 64) acc = fmaf(row[c], delta[c], acc);
+    for (int c = lane; c < Din; c += 64) {
+      const float d = sums ? (float)(sums[c] / ns) - (float)(sums[Din + c] / nt) : delta[c];
+      acc = fmaf(row[c], d, acc);
+    }
     acc = bgnn::group_sum<64>(acc);
     if (lane == 0) { if (j < NC) wd[j] = acc; else gc[j - NC] = acc + (gate_const ? gate_const[j - NC] : 0.f); }
   }
@@ -770,7 +777,8 @@ extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int6
   const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = DS_NT / cw;
   // 2*Din device-scope fp64 atomics per block at ~3 G/s: a block must stream >= 2048 rows to amortise them (a rank's
   // share of a partitioned graph is small), and never more blocks than CUs
-  int64_t grid = (N + 2047) / 2048;
+  static const int64_t rpb = [] { const char* e = getenv("BGNN_DS_ROWS"); return e ? atoll(e) : 2048ll; }();
+  int64_t grid = (N + rpb - 1) / rpb;
   static const int64_t gcap = [] { const char* e = getenv("BGNN_DS_GRID"); return e ? atoll(e) : 256ll; }();
   if (grid > gcap) grid = gcap;
   if (grid < 1) grid = 1;
@@ -788,23 +796,23 @@ extern "C" int bgnn_domain_delta_f32(const double* sums, int32_t Din, float* del
   return 0;
 }
 
-extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
-                                              const uint8_t* mask, const float* delta,
-                                              int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
-                                              const float* gates, const float* gate_const_opt,
-                                              float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                                              int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
-  if (!x || !mask || !delta || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
+static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                          const uint8_t* mask, const float* delta, const double* sums,
+                          int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                          const float* gates, const float* gate_const_opt,
+                          float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                          int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
+  if (!x || !mask || (!delta && !sums) || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
   if (n_heads < 1 || n_heads > MAXH || (n_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
   if (N < 0 || Din <= 0 || D <= 0 || ldx < Din || ldh < D) return BGNN_E_SHAPE;
   if ((Din & 3) || (ldx & 3) || (ldh & 3) || (row_stride & 3) || row_stride < ldh) return BGNN_E_SHAPE;
-  if (!bgnn_aligned16(x) || !bgnn_aligned16(Wp) || !bgnn_aligned16(delta) || !bgnn_aligned16(gates)) return BGNN_E_ALIGN;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(Wp) || !bgnn_aligned16(gates)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int NC = n_heads * 2 * (int)ldh;
   float* wd = small_ws;            // [NC]
   float* gc = small_ws + NC;       // [n_heads*2]
-  hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((NC + 2 * n_heads + 3) / 4)), dim3(256), 0, st, Wp, NC, Din, delta, gates,
+  hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((NC + 2 * n_heads + 3) / 4)), dim3(256), 0, st, Wp, NC, Din, delta, sums, gates,
                      gate_const_opt, n_heads, wd, gc);
   BGNN_LAUNCH_CHECK();
   GemmParams p;
@@ -851,6 +859,29 @@ extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t
   }
   BGNN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                              const uint8_t* mask, const float* delta,
+                                              int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                              const float* gates, const float* gate_const_opt,
+                                              float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                              int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
+  if (!delta) return BGNN_E_NULL;
+  if (!bgnn_aligned16(delta)) return BGNN_E_ALIGN;
+  return transform_impl(x, N, Din, ldx, mask, delta, nullptr, n_heads, D, Wp, bias_p, gates, gate_const_opt,
+                        h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream);
+}
+
+extern "C" int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                                   const uint8_t* mask, const double* sums,
+                                                   int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                                   const float* gates, const float* gate_const_opt,
+                                                   float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                                   int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
+  if (!sums) return BGNN_E_NULL;
+  return transform_impl(x, N, Din, ldx, mask, nullptr, sums, n_heads, D, Wp, bias_p, gates, gate_const_opt,
+                        h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream);
 }
 
 extern "C" int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,

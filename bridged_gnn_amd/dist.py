@@ -248,21 +248,20 @@ class PartitionedKTGNN:
             self._states = {**self._states, key: st} if len(self._states) < 8 else {key: st}
         return st
 
-    def _conv(self, conv, x, epilogue=None, sums=None, out_sums=None):
+    def _conv(self, conv, x, epilogue=None, sums=None, out_sums=None, arena=None):
         from . import ops
         from .ktgnn import _pad_cols4
         p = self.plan
         xp = _pad_cols4(x)
         if sums is None:
-            sums = ops.domain_sums(xp, self.mask_u8)
+            sums = ops.domain_sums(xp, self.mask_u8, out=arena.take(2 * xp.shape[1] + 2) if arena is not None else None)
             if self.world > 1 or self.always:
                 sums = self._all_reduce(sums)                        # 2*Din+2 doubles
-        delta = ops.domain_delta(sums, xp.shape[1])
         ld = ops.pad4(conv.out_channels)
         # one allocation per conv: [h_s2t local | h_t2s local | halo]; the transform writes both local parts
         big = torch.empty(2 * p.n_local + p.n_halo, ld, dtype=torch.float32, device=self.device)
         h_t2s, h_s2t = p.table_views(big)
-        conv.transform(x, self.mask_u8, delta=delta, out=(h_t2s, h_s2t))   # writes rows [0, n_local) of each view
+        conv.transform(x, self.mask_u8, sums=sums, out=(h_t2s, h_s2t))     # writes rows [0, n_local) of each view
         self.halo.start(big)
         a_t2s = conv.a_f_t2s.weight.detach().reshape(-1).contiguous()
         a_s2t = conv.a_f_s2t.weight.detach().reshape(-1).contiguous()
@@ -281,17 +280,24 @@ class PartitionedKTGNN:
             raise NotImplementedError("partitioned forward is eval-only (BN batch statistics would need an all-reduce)")
         from . import ops
         x = x_local.float().contiguous()
-        s_h = None
+        s_h = both = None
+        # every float64 accumulator of this forward comes out of ONE zero fill; the two sums that travel in the
+        # classifier stage's all-reduce (of h and of T's hidden activation) sit next to each other in it
+        width = max([x.shape[1]] + [c.out_channels for c in m.convs])
+        arena = ops.ZeroArena(self.device, (len(m.convs) + 3) * (2 * ops.pad4(width) + 2))
         for ind, conv in enumerate(m.convs):
             if m.use_bn:
                 from .ktgnn import bn_eval_affine
                 sc, sh = bn_eval_affine(m.bns[ind])
                 last = ind == len(m.convs) - 1
                 # fused sums in the epilogue (one pass fewer over the rank-local activations; neutral on one GPU)
-                s_h = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=self.device) if last else None
-                x, _ = self._conv(conv, x, epilogue=(sc, sh, True), out_sums=s_h)   # epilogue also sums the finished rows
+                if last:
+                    n_h = 2 * ops.pad4(conv.out_channels) + 2
+                    both = arena.take(2 * n_h)
+                    s_h = both[:n_h]
+                x, _ = self._conv(conv, x, epilogue=(sc, sh, True), out_sums=s_h, arena=arena)   # epilogue also sums the finished rows
             else:
-                x, _ = self._conv(conv, x)
+                x, _ = self._conv(conv, x, arena=arena)
                 x = F.relu(x)
             x = x.contiguous()
         # the two classifier inputs (h and T(h)) are both row-local once the hidden conv is done: their domain
@@ -299,17 +305,21 @@ class PartitionedKTGNN:
         from . import ops
         from .ktgnn import _pad_cols4
         # h1; T's last Linear is folded into the conv weights; its rank-local domain sums come out of the GEMM epilogue
-        xt, s_t = m._transformer_hidden_eval(x, self.mask_u8, want_sums=True)
+        adjacent = both is not None and x.shape[1] == m.clf_transformer[0].weight.shape[0]
+        xt, s_t = m._transformer_hidden_eval(x, self.mask_u8, want_sums=True, sums_out=both[s_h.numel():] if adjacent else None)
         xt = xt.contiguous()
         if s_h is None:
             s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
         if s_t is None or s_t.numel() != 2 * _pad_cols4(xt).shape[1] + 2:
             s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
-        both = torch.cat((s_h, s_t))
+        if not (adjacent and s_t.data_ptr() == both[s_h.numel():].data_ptr()):
+            both = torch.cat((s_h, s_t))
         if self.world > 1 or self.always:
             both = self._all_reduce(both)
-        s_h, s_t = both[: s_h.numel()].contiguous(), both[s_h.numel():].contiguous()
-        logp = F.log_softmax(self._classifier_stage(x, xt, s_h, s_t), dim=2)     # one launch for the three heads
+        s_h, s_t = both[: s_h.numel()], both[s_h.numel():]
+        logp, fused = self._classifier_stage(x, xt, s_h, s_t)
+        if not fused:
+            logp = F.log_softmax(logp, dim=2)                                    # one launch for the three heads
         return logp[:, 0], logp[:, 1], logp[:, 2]
 
     def _classifier_stage(self, x, xt, s_h, s_t):
@@ -324,11 +334,9 @@ class PartitionedKTGNN:
         ld = ops.pad4(C)
         big = torch.empty(2 * p.n_local + p.n_halo, 3 * ld, dtype=torch.float32, device=self.device)
         views = [(big[p.n_local:, j * ld:(j + 1) * ld], big[:, j * ld:(j + 1) * ld]) for j in range(3)]   # (h_t2s, h_s2t)
-        d_h = ops.domain_delta(s_h, _pad_cols4(x).shape[1])
-        d_t = ops.domain_delta(s_t, _pad_cols4(xt).shape[1])
-        m.clf_base.transform(x, self.mask_u8, delta=d_h, partner=m.clf_target, out=[views[0], views[1]])
+        m.clf_base.transform(x, self.mask_u8, sums=s_h, partner=m.clf_target, out=[views[0], views[1]])
         xtp = _pad_cols4(xt)
-        ops.adaptedconv_transform(xtp, self.mask_u8, d_t, m._composed_target_pack(xtp.shape[1]), out=[views[2]])
+        ops.adaptedconv_transform(xtp, self.mask_u8, None, m._composed_target_pack(xtp.shape[1]), out=[views[2]], sums=s_t)
         self.halo.start(big)
         akey = (m.clf_base._versions(), m.clf_target._versions())
         if getattr(m, "_a3_key", None) != akey:                      # same cache as the single-GPU forward
@@ -342,7 +350,8 @@ class PartitionedKTGNN:
         st = self._state3
         if st is None or st.shape[0] < 3 * p.n_local:
             st = self._state3 = torch.empty(3 * p.n_local, 2, dtype=torch.float32, device=self.device)
-        kw = dict(n_dst=p.n_local, out=out3, heads=3)
+        fused = ops.heads_log_softmax_supported(3, C)                # KTGNN.py:435 in the epilogue of the finishing launches
+        kw = dict(n_dst=p.n_local, out=out3, heads=3, log_softmax=fused)
         slope = m.clf_base.negative_slope
         ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_L, self.mask_u8, C, slope,
                                   row_begin=0, row_end=p.n_interior, **kw)
@@ -351,4 +360,4 @@ class PartitionedKTGNN:
         self.halo.wait()
         ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_R, self.mask_u8, C, slope,
                                   row_begin=p.n_interior, row_end=p.n_local, state_ms=st, part=2, **kw)
-        return out3.view(p.n_local, 3, ld)[:, :, :C]                 # [n_local, 3, C]: base, target, target-hat
+        return out3.view(p.n_local, 3, ld)[:, :, :C], fused          # [n_local, 3, C]: base, target, target-hat

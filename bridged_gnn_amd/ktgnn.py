@@ -259,12 +259,12 @@ class AdaptedConv(nn.Module):
         input) -> [(h_t2s, h_s2t), (h_t2s', h_s2t')] from one pass over x."""
         xp = _pad_cols4(x)
         din_pad = xp.shape[1]
-        if delta is None:
-            if sums is None:
-                sums = ops.domain_sums(xp, mask_u8)
-            delta = ops.domain_delta(sums, din_pad)
+        if delta is None and sums is None:
+            sums = ops.domain_sums(xp, mask_u8)
+        # with `sums` the kernel that forms W.delta also forms delta (bgnn_adaptedconv_transform_sums_f32)
         res = ops.adaptedconv_transform(xp, mask_u8, delta, self.packed(din_pad, partner),
-                                        out=out if (out is None or partner is not None) else [out])
+                                        out=out if (out is None or partner is not None) else [out],
+                                        sums=sums if delta is None else None)
         return res if partner is not None else res[0]
 
     def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None, colsum=None):
@@ -369,6 +369,7 @@ class KTGNN_no_complement(nn.Module):
             Linear(hidden, hidden, bias=True), nn.BatchNorm1d(hidden), nn.ReLU(), Linear(hidden, hidden, bias=True))
         self.edge_index1 = self.edge_index2 = self.edge_index = None
         self._csr = None
+        self._arena = None
 
     def reset_parameters(self):
         for conv in self.convs:
@@ -403,7 +404,7 @@ class KTGNN_no_complement(nn.Module):
             self._csr = csr
         return csr
 
-    def _hidden(self, x, csr, central_mask, want_sums=False):
+    def _hidden(self, x, csr, central_mask, want_sums=False, arena=None):
         """hidden stack (KTGNN.py:418-430).  On the fused eval path every conv's aggregation epilogue also accumulates
         the per-domain column sums of its output, i.e. the domain sums (KTGNN.py:275) of the NEXT conv's input, so
         only the first conv streams its input an extra time; `want_sums` returns the last conv's."""
@@ -412,8 +413,12 @@ class KTGNN_no_complement(nn.Module):
             sums_in, sums = sums, None
             if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters())):
                 sc, sh = bn_eval_affine(self.bns[ind])
+                if arena is None:                      # every float64 accumulator of this forward from one zero fill
+                    arena = ops.ZeroArena(x.device, (len(self.convs) + 3) * (2 * ops.pad4(max(x.shape[1], conv.out_channels)) + 2))
+                if sums_in is None and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0:
+                    sums_in = ops.domain_sums(x, _as_u8(central_mask).contiguous(), out=arena.take(2 * x.shape[1] + 2))
                 if not (conv.root_weight or conv.normalize):
-                    sums = torch.zeros(2 * ops.pad4(conv.out_channels) + 2, dtype=torch.float64, device=x.device)
+                    sums = arena.take(2 * ops.pad4(conv.out_channels) + 2)
                 x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
             else:
                 x = conv(x, None, central_mask=central_mask, csr=csr, sums=sums_in)
@@ -421,9 +426,10 @@ class KTGNN_no_complement(nn.Module):
                     x = self.bns[ind](x)
                 x = F.relu(x)
                 x = F.dropout(x, p=self.dropout, training=self.training)
+        self._arena = arena
         return (x, sums) if want_sums else x
 
-    def _transformer_hidden_eval(self, x, mask_u8=None, want_sums=False):
+    def _transformer_hidden_eval(self, x, mask_u8=None, want_sums=False, sums_out=None):
         """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded: BN(Wx+b) = (s*W)x + (s*b + t)).  Inside the
         envelope of `ops.linear` the W-stationary MFMA kernel applies bias + ReLU and, with `want_sums`, accumulates the
         per-domain column sums of h1 in its epilogue; other shapes go through the library GEMM."""
@@ -441,7 +447,7 @@ class KTGNN_no_complement(nn.Module):
         dout, din = self._tf_w0.shape
         if x.dtype == torch.float32 and x.stride(1) == 1 and ops.linear_supported(din, dout):
             if want_sums:
-                sums = torch.zeros(2 * dout + 2, dtype=torch.float64, device=x.device)
+                sums = sums_out if sums_out is not None else torch.zeros(2 * dout + 2, dtype=torch.float64, device=x.device)
             h1 = ops.linear(x, self._tf_w0, self._tf_b0, relu=True, mask_u8=mask_u8 if want_sums else None, colsum=sums)
         elif hasattr(torch, "_addmm_activation"):
             h1 = torch._addmm_activation(self._tf_b0, x, self._tf_w0t, use_gelu=False)
@@ -502,19 +508,25 @@ class KTGNN_no_complement(nn.Module):
             self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
             # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
             # h1 = relu(BN(Linear0(x))) is materialised
-            h1, sums1 = self._transformer_hidden_eval(x, mask_u8, want_sums=True)
+            arena = self._arena
+            h1, sums1 = self._transformer_hidden_eval(
+                x, mask_u8, want_sums=True, sums_out=arena.take(2 * x.shape[1] + 2) if arena is not None else None)
             h1p = _pad_cols4(h1)
-            d1 = ops.domain_delta(sums1 if sums1 is not None else ops.domain_sums(h1p, mask_u8), h1p.shape[1])
-            ops.adaptedconv_transform(h1p, mask_u8, d1, self._composed_target_pack(h1p.shape[1]), out=[views[2]])
+            if sums1 is None:
+                sums1 = ops.domain_sums(h1p, mask_u8)
+            ops.adaptedconv_transform(h1p, mask_u8, None, self._composed_target_pack(h1p.shape[1]), out=[views[2]], sums=sums1)
             akey = (self.clf_base._versions(), self.clf_target._versions())
             if getattr(self, "_a3_key", None) != akey:           # stacked attention vectors, re-packed when a weight changes
                 cs = (self.clf_base, self.clf_target, self.clf_target)
                 self._a3 = (torch.stack([c.a_f_t2s.weight.detach().reshape(-1) for c in cs]).contiguous(),
                             torch.stack([c.a_f_s2t.weight.detach().reshape(-1) for c in cs]).contiguous())
                 self._a3_key = akey
+            fused = ops.heads_log_softmax_supported(3, C)          # :435 inside the aggregation's epilogue
             out3 = ops.adaptedconv_aggregate(t2s, s2t, self._a3[0], self._a3[1], csr, mask_u8, C,
-                                             self.clf_base.negative_slope, heads=3)
-            logp = F.log_softmax(out3.view(N, 3, ld)[:, :, :C], dim=2)                                  # one launch for :435
+                                             self.clf_base.negative_slope, heads=3, log_softmax=fused)
+            logp = out3.view(N, 3, ld)[:, :, :C]
+            if not fused:
+                logp = F.log_softmax(logp, dim=2)                                                       # one launch for :435
             return logp[:, 0], logp[:, 1], logp[:, 2], None                                             # :432,:434,:433
         return (F.log_softmax(logits_base, dim=1), F.log_softmax(logits_target, dim=1),
                 F.log_softmax(logits_hat, dim=1), None)                                                  # :435

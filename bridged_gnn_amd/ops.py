@@ -62,11 +62,29 @@ def build_dst_csr(edge_index, num_nodes, rewrite_self_loops=True, want_eperm=Fal
     return DstCSR(rowptr, col[:ne], eperm[:ne] if want_eperm else None, ne, N)
 
 
-def domain_sums(x, mask_u8):
-    """Per-domain column sums + counts as a float64 [2*Din+2] tensor (all-reducible)."""
+class ZeroArena:
+    """One zero-filled float64 allocation per forward that hands out the [2*Din+2] accumulators of `domain_sums` and of
+    the `colsum` epilogues (one fill launch instead of one per accumulator)."""
+
+    def __init__(self, device, doubles):
+        self.buf = torch.zeros(int(doubles), dtype=torch.float64, device=device)
+        self.used = 0
+
+    def take(self, n):
+        n = int(n)
+        if self.used + n > self.buf.numel():            # undersized arena: still correct, one more fill
+            return torch.zeros(n, dtype=torch.float64, device=self.buf.device)
+        t = self.buf[self.used: self.used + n]
+        self.used += (n + 1) // 2 * 2                   # keep slices 16-byte aligned
+        return t
+
+
+def domain_sums(x, mask_u8, out=None):
+    """Per-domain column sums + counts as a float64 [2*Din+2] tensor (all-reducible).  `out`: zero-filled accumulator."""
     lib = L.lib()
     N, Din = x.shape
-    sums = torch.zeros(2 * Din + 2, dtype=torch.float64, device=x.device)
+    sums = torch.zeros(2 * Din + 2, dtype=torch.float64, device=x.device) if out is None else out
+    assert sums.numel() == 2 * Din + 2 and sums.dtype == torch.float64
     rc = lib.bgnn_domain_sums_f64(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(sums), L.stream())
     L.check(rc, "bgnn_domain_sums_f64")
     return sums
@@ -155,10 +173,11 @@ def pack_transform_heads(heads, din_pad):
     return Wp, bp, gates, D, ldh, gconst
 
 
-def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
+def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None):
     """One pass over x -> per head (h_t2s, h_s2t) as [N, ldh] tensors (ldh = pad4(D); columns >= D are
     zero).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
-    (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows)."""
+    (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows).  With `delta=None` the domain
+    `sums` ([2*Din+2] float64) are consumed directly (same delta, one launch less)."""
     lib = L.lib()
     Wp, bp, gates, D, ldh, gconst = packed
     H = gates.shape[0]
@@ -172,11 +191,16 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None):
         assert a.shape[0] >= N and b.shape[0] >= N and a.stride(0) == row_stride and b.stride(0) == row_stride
     small = torch.empty(H * (2 * ldh + 2) + 8, dtype=torch.float32, device=dev)
     o1 = out[1] if H > 1 else (None, None)
-    rc = lib.bgnn_adaptedconv_transform_f32(
-        L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(delta), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates), L.ptr(gconst),
-        L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride,
-        L.ptr(small), L.stream())
-    L.check(rc, "bgnn_adaptedconv_transform_f32")
+    if delta is None:
+        if sums is None or sums.dtype != torch.float64 or sums.numel() != 2 * Din + 2:
+            raise ValueError("adaptedconv_transform needs delta [Din] or the float64 domain sums [2*Din+2]")
+        fn, first, name = lib.bgnn_adaptedconv_transform_sums_f32, sums, "bgnn_adaptedconv_transform_sums_f32"
+    else:
+        fn, first, name = lib.bgnn_adaptedconv_transform_f32, delta, "bgnn_adaptedconv_transform_f32"
+    rc = fn(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(first), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates), L.ptr(gconst),
+            L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride,
+            L.ptr(small), L.stream())
+    L.check(rc, name)
     return out
 
 
@@ -192,10 +216,17 @@ def _tile_queue(dev):
     return q
 
 
+def heads_log_softmax_supported(heads, D):
+    """Envelope of the fused log_softmax epilogue (bgnn.h: ep_relu == 2)."""
+    return heads in (2, 3) and D <= 4
+
+
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
-                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None):
+                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None, log_softmax=False):
     """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order.
+    `log_softmax` (interleaved narrow heads only, see `heads_log_softmax_supported`): the finished rows leave the kernel
+    as log_softmax over each head's D classes (KTGNN.py:435).
     Only rows [row_begin, row_end) are computed (default: all n_dst rows).
     heads > 1: tables are [rows, heads*pad4(D)] (heads interleaved per node), a_* are [heads, D], out is
     [n_dst, heads*pad4(D)]: one pass over the CSR serves all heads."""
@@ -214,7 +245,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
-        L.ptr(ep_scale), L.ptr(ep_shift), 1 if ep_relu else 0, L.ptr(state_ms), int(part), int(heads), L.ptr(colsum),
+        L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part), int(heads), L.ptr(colsum),
         L.ptr(_tile_queue(dev)) if heads == 1 else None, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out

@@ -101,6 +101,14 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
                                    const float* gates, const float* gate_const_opt,
                                    float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                                    int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
+/* Same transform taking the domain sums ([2*Din+2] doubles, after any all-reduce) instead of delta: the tiny
+ * W.delta kernel forms delta with the arithmetic of bgnn_domain_delta_f32 (bit-identical), one launch less per conv. */
+int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                        const uint8_t* mask, const double* sums,
+                                        int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                        const float* gates, const float* gate_const_opt,
+                                        float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                        int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
@@ -114,7 +122,9 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
  * One pass over the in-neighbours with an online softmax: every H row is read once per edge.
  * Feature tables may have more rows than row_end (multi-GPU: local rows then halo rows).
  * Optional fused node-wise epilogue of KTGNN_no_complement.forward (:425-430, eval mode):
- *   out = relu?(out * ep_scale[c] + ep_shift[c])  (BatchNorm1d eval affine; NULL = identity).
+ *   out = relu?(out * ep_scale[c] + ep_shift[c])  (BatchNorm1d eval affine; NULL = identity); ep_relu: 0 none, 1 ReLU,
+ *   2 = log_softmax over the D classes of every head (:435; interleaved narrow heads only: heads in {2,3}, D <= 4,
+ *   ldh == ldo == 4; like ReLU it applies when a row is finished, i.e. not in part = 1).
  * alpha_opt ([E'] in CSR order) is optional (tests / backward).
  * Two-part rows (multi-GPU overlap): part = 1 visits a row's first edge list and parks the online-softmax state
  * ((max, sum) in state_ms_opt [rows][2], the raw accumulator in out); part = 2 resumes from it over a second

@@ -200,6 +200,54 @@ def test_transform_fuzz_vs_c_oracle(seed):
     assert float(h_t2s[:, D:].abs().max()) == 0.0 if h_t2s.shape[1] > D else True     # pad columns stay exactly zero
 
 
+@pytest.mark.parametrize("din,D,n", [(128, 128, 3000), (36, 2, 1234), (300, 31, 700)])
+def test_transform_from_sums_is_bit_identical(din, D, n):
+    """bgnn_adaptedconv_transform_sums_f32 (delta formed inside the W.delta kernel) == domain_delta + transform."""
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.ktgnn import AdaptedConv, _as_u8, _pad_cols4
+    rng = np.random.default_rng(din * 7 + D)
+    mask = _as_u8(_t(rng.random(n) < 0.4))
+    x = _pad_cols4(_t(rng.standard_normal((n, din)).astype(np.float32)))
+    torch.manual_seed(1)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV).eval()
+    with torch.no_grad():
+        sums = ops.domain_sums(x, mask)
+        a = conv.transform(x, mask, delta=ops.domain_delta(sums, x.shape[1]))
+        b = conv.transform(x, mask, sums=sums)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        ops.adaptedconv_transform(x, mask, None, conv.packed(x.shape[1], None), sums=sums[:-1])
+
+
+@pytest.mark.parametrize("C,heads", [(2, 3), (3, 3), (4, 2), (1, 3)])
+def test_heads_log_softmax_epilogue(C, heads):
+    """ep_relu == 2: the interleaved narrow-heads aggregation finishes rows as log_softmax (KTGNN.py:435)."""
+    from bridged_gnn_amd import ops, synth
+    n = 3000
+    ei, mask = synth.random_multigraph(n, 30000, frac_src=0.5, seed=C)
+    csr = ops.build_dst_csr(_t(ei), n)
+    m8 = _t(mask).to(torch.uint8)
+    g = torch.Generator(device=DEV).manual_seed(C)
+    ld = ops.pad4(C)
+    t2s = torch.zeros(n, heads * ld, device=DEV)
+    s2t = torch.zeros(n, heads * ld, device=DEV)
+    for h in range(heads):
+        t2s[:, h * ld: h * ld + C] = torch.randn(n, C, device=DEV, generator=g) * 3
+        s2t[:, h * ld: h * ld + C] = torch.randn(n, C, device=DEV, generator=g) * 3
+    a1 = torch.randn(heads, C, device=DEV, generator=g)
+    a2 = torch.randn(heads, C, device=DEV, generator=g)
+    plain = ops.adaptedconv_aggregate(t2s, s2t, a1, a2, csr, m8, C, 0.1, heads=heads)
+    fused = ops.adaptedconv_aggregate(t2s, s2t, a1, a2, csr, m8, C, 0.1, heads=heads, log_softmax=True)
+    want = torch.log_softmax(plain.view(n, heads, ld)[:, :, :C].double(), dim=2)
+    got = fused.view(n, heads, ld)
+    assert_close(got[:, :, :C].cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, what="fused log_softmax")
+    if ld > C:
+        assert float(got[:, :, C:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):             # outside the envelope the ABI refuses instead of ignoring the flag
+        ops.adaptedconv_aggregate(torch.randn(n, 64, device=DEV), torch.randn(n, 64, device=DEV), torch.randn(64, device=DEV),
+                                  torch.randn(64, device=DEV), csr, m8, 64, 0.1, log_softmax=True)
+
+
 def test_graph_replay_matches_eager():
     """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
     order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""
