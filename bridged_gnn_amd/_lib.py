@@ -24,13 +24,13 @@ SIGNATURES = {
     "bgnn_adaptedconv_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
                                                _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "bgnn_adaptedconv_transform_sums_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
-                                                    _P, _P, _P, _P, _I64, _I64, _P, _P]),
+                                                    _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
     "bgnn_gram_f32": (_INT, [_P, _I64, _I32, _P, _I64, _I32, _I64, _P, _P, C.c_size_t, _P]),
     "bgnn_rowdot_f32": (_INT, [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "bgnn_linear_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _I64, _P]),
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
-                                               _P, _I64, _P, _P, _P, _INT, _P, _INT, _I32, _P, _P, _P]),
+                                               _P, _I64, _P, _P, _P, _INT, _P, _INT, _I64, _I32, _P, _P, _P]),
     "bgnn_adaptedconv_aggregate_bwd_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
                                                    _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "bgnn_aggregate_bwd_pull_workspace_bytes": (C.c_size_t, [_I64, _I64, _I64]),
@@ -42,6 +42,7 @@ SIGNATURES = {
     "bgnn_mlp_pair_topk_f32": (_INT, [_P, _P, _P, _P, _P, _F32, _I64, _I64, _I32, _I32, _INT, _P, _P, _P,
                                        _P, _SZ, _P]),
     "bgnn_topk_edges_i64": (_INT, [_P, _I64, _I32, _I64, _I64, _P, _P]),
+    "bgnn_gather_rows_f32": (_INT, [_P, _I64, _I64, _P, _I64, _I32, _P, _I64, _P]),
     "bgnn_coalesce_workspace_bytes": (_SZ, [_I64]),
     "bgnn_coalesce_i64": (_INT, [_P, _I64, _I64, _P, _P, _SZ, _P]),
 }

@@ -13,6 +13,7 @@
 //   D=4  : LF=1,  EP=8 -> 8 rows per wave, each lane owns whole (16-B) neighbour rows.
 // Blocks are persistent over an XCD-contiguous range of row tiles so neighbouring destination
 // rows (which share in-neighbours in a bridged / kNN graph) hit the same XCD's L2.
+#include <cstdlib>
 #include "bgnn_common.h"
 
 namespace {
@@ -47,6 +48,8 @@ struct AggParams {
   float* state_ms;   // [rows][2] running (max, sum) of a row whose edges are visited in two launches
   int mode;          // 0: one launch; 1: first part -> leave (m, s) in state_ms and the raw accumulator in out;
                      // 2: second part -> resume from them, then normalise + epilogue
+  int64_t park_begin;  // mode 1: nodes below it have no second part and are finished (normalise + epilogue) right away
+  int tq_chunk;      // consecutive tiles per queue claim (AGG_TQ_CHUNK; 1 for launches of only a few tiles per block)
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   const int64_t xbase = tr.begin - (blockIdx.x / 8);        // first tile of this XCD's range
   int64_t tile = tr.begin - tr.step;
   int64_t chunk_left = 0;
-  constexpr int TQ_CHUNK = 4;                               // tiles per queue fetch (see agg_wide_kernel)
+  const int TQ_CHUNK = p.tq_chunk;                          // tiles per queue fetch (see agg_wide_kernel)
   for (;;) {
     if (p.tile_queue != nullptr) {                          // kernel-uniform
       if (chunk_left == 0) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       m = mn;
     }
 
-    if (p.mode == 1) {                            // first part only: park the online-softmax state
+    if (p.mode == 1 && node >= p.park_begin) {    // first part only: park the online-softmax state
       if (rvalid && sub == 0) {
         if (lg == 0) { p.state_ms[2 * i] = m; p.state_ms[2 * i + 1] = s; }
         if (f0 < p.ldo) *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) = fvalid ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,10 +318,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   // The queue hands out CHUNKS of TQ_CHUNK consecutive tiles: device-scope atomics on ONE address retire at only
   // ~11 M/s (90 ns each, measured), so one atomic per 8-row tile put a floor of 125k tiles x 90 ns / 8 queues = 1.4 ms
   // under the C4 launch -- the kernel took 1.45 ms for 1 to 42 in-edges per row alike.
-#ifndef AGG_TQ_CHUNK
-#define AGG_TQ_CHUNK 4
-#endif
-  constexpr int TQ_CHUNK = AGG_TQ_CHUNK;
+  const int TQ_CHUNK = p.tq_chunk;
   int64_t tile = tr.begin - tr.step;
   int64_t chunk_left = 0;
   for (;;) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
     s += bgnn::dpp_mov<0x4E>(s);
     if constexpr (U == 8) s += bgnn::dpp_mov<0x124>(s);
 
-    if (p.mode == 1) {
+    if (p.mode == 1 && node >= p.park_begin) {
       if (rvalid) {
         if (lg == 0) { p.state_ms[2 * i] = m; p.state_ms[2 * i + 1] = s; }
         if (f0 < p.ldo)
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
       }
       if (rvalid && sub == 0) {
         float* o = p.out + (i * HEADS + h) * p.ldo;
-        if (p.mode == 1) {
+        if (p.mode == 1 && i >= p.park_begin) {
           p.state_ms[2 * (i * HEADS + h)] = m[h];
           p.state_ms[2 * (i * HEADS + h) + 1] = s[h];
           *reinterpret_cast<float4*>(o) = acc[h];
@@ -636,6 +636,14 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
       }
     }
   }
+}
+
+// Tiles per queue claim.  4 amortises the same-address atomic (~90 ns each); measured on a rank's share of C4
+// (tools/rank_of_8_time.py): 1 -> 0.80 ms, 2 -> 0.69, 4 -> 0.67, 8 -> 0.70 per forward, also for the short launches.
+inline int tq_chunk_for(int64_t ntiles, int64_t grid) {
+  static const int forced = [] { const char* e = getenv("BGNN_AGG_CHUNK"); return e ? atoi(e) : 0; }();
+  (void)ntiles; (void)grid;
+  return forced > 0 ? forced : 4;
 }
 
 template <int HEADS, int EP, int U>
@@ -681,7 +689,9 @@ int launch(const AggParams& p, hipStream_t st) {
   const int64_t cap = resident_blocks<LF, EP, U>();
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;   // multiple of 8 (XCD split)
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((agg_kernel<LF, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  AggParams q = p;
+  q.tq_chunk = tq_chunk_for(ntiles, grid);
+  hipLaunchKernelGGL((agg_kernel<LF, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
@@ -700,7 +710,9 @@ int launch_wide(const AggParams& p, hipStream_t st) {
   const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  AggParams q = p;
+  q.tq_chunk = tq_chunk_for(ntiles, grid);
+  hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
@@ -713,9 +725,10 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                               float* out, int64_t ldo, float* alpha_opt,
                                               const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                              float* state_ms_opt, int part, int32_t heads, double* colsum_opt,
-                                              uint32_t* tile_queue_opt, void* stream) {
-  if (colsum_opt && (heads != 1 || part == 1)) return BGNN_E_SHAPE;
+                                              float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
+                                              double* colsum_opt, uint32_t* tile_queue_opt, void* stream) {
+  if (colsum_opt && heads != 1) return BGNN_E_SHAPE;
+  if (part == 1 && (park_begin < row_begin || park_begin > row_end)) return BGNN_E_SHAPE;
   if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
   if (heads < 1 || heads > 8 || (heads > 1 && (alpha_opt || ep_scale_opt))) return BGNN_E_SHAPE;
   if (ep_relu < 0 || ep_relu > 2) return BGNN_E_SHAPE;
@@ -728,7 +741,8 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
   if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
   if (row_end == row_begin) return 0;
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
-              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part};
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part,
+              park_begin, 4};
   hipStream_t st = (hipStream_t)stream;
   if (tile_queue_opt) {
     hipError_t e = hipMemsetAsync(tile_queue_opt, 0, 8 * sizeof(uint32_t), st);

@@ -227,3 +227,33 @@ extern "C" int bgnn_topk_edges_i64(const int64_t* idx, int64_t Nq, int32_t k, in
   BGNN_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------ row packing (halo send lists)
+namespace {
+// one thread per 16-byte chunk: a wave reads whole rows (or several narrow rows) and writes one contiguous span
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                          const int64_t* __restrict__ idx, int64_t n, int32_t c4,
+                                                          int64_t src_rows, float* __restrict__ dst, int64_t ld_dst) {
+  const int64_t total = n * c4;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / c4;
+    const int c = (int)(t - r * c4);
+    int64_t s = idx[r];
+    s = s < 0 ? 0 : (s >= src_rows ? src_rows - 1 : s);     // an index outside the table must not become a fault
+    *reinterpret_cast<float4*>(dst + r * ld_dst + 4 * c) = *reinterpret_cast<const float4*>(src + s * ld_src + 4 * c);
+  }
+}
+}  // namespace
+
+extern "C" int bgnn_gather_rows_f32(const float* src, int64_t src_rows, int64_t ld_src, const int64_t* idx, int64_t n,
+                                    int32_t row_floats, float* dst, int64_t ld_dst, void* stream) {
+  if (n == 0) return 0;                        // an empty send list has no storage behind its pointers
+  if (!src || !idx || !dst) return BGNN_E_NULL;
+  if (n < 0 || src_rows <= 0 || row_floats <= 0 || (row_floats & 3) || ld_src < row_floats || ld_dst < row_floats) return BGNN_E_SHAPE;
+  if ((ld_src & 3) || (ld_dst & 3) || !bgnn_aligned16(src) || !bgnn_aligned16(dst)) return BGNN_E_ALIGN;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * (row_floats / 4))), dim3(256), 0, (hipStream_t)stream,
+                     src, ld_src, idx, n, row_floats / 4, src_rows, dst, ld_dst);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}

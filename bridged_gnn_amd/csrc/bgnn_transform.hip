@@ -145,6 +145,7 @@ struct GemmParams {
   int64_t ldh; int64_t row_stride; int32_t NC; int32_t n_heads;   // ldh = padded width of a head's row, row_stride >= ldh
   int32_t relu;         // plain-linear mode (transform_wreg_kernel<.., MODE = 1>): out = relu?(x W^T + b)
   double* colsum;       // plain-linear mode, optional [2*NC + 2]: per-domain column sums (+ node counts) of the output
+  int32_t col_off;      // transform_wreg_kernel: the launch covers the packed columns [col_off, NC) (one table of a head)
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, clean waitcnt placement
   const int fr = lane & 31, fh = lane >> 5;
   const int ct = wave % NCT, rs = wave / NCT;
-  const int col_base = blockIdx.y * (32 * NCT) + ct * 32;
-  // (host guarantees NC % (32 * NCT) == 0: every wave owns a full column tile -- no per-wave branches in the tile loop,
+  const int col_base = p.col_off + blockIdx.y * (32 * NCT) + ct * 32;
+  // (host guarantees (NC - col_off) % (32 * NCT) == 0: every wave owns a full column tile -- no per-wave branches in the tile loop,
   //  which keeps the compiler's s_waitcnt placement exact)
 
   // ---- stationary operands -------------------------------------------------------------------------------
@@ -801,7 +802,9 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
                           int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
                           const float* gates, const float* gate_const_opt,
                           float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                          int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
+                          int64_t ldh, int64_t row_stride, float* small_ws, void* stream,
+                          int64_t n_tail_t2s = 0, int64_t n_tail_s2t = 0) {
+  if (n_tail_t2s < 0 || n_tail_s2t < 0 || n_tail_t2s + n_tail_s2t > N) return BGNN_E_SHAPE;
   if (!x || !mask || (!delta && !sums) || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
   if (n_heads < 1 || n_heads > MAXH || (n_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
   if (N < 0 || Din <= 0 || D <= 0 || ldx < Din || ldh < D) return BGNN_E_SHAPE;
@@ -818,7 +821,7 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
   GemmParams p;
   p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;
   p.out[0][0] = h_s2t_0; p.out[0][1] = h_t2s_0; p.out[1][0] = h_s2t_1; p.out[1][1] = h_t2s_1;
-  p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads; p.relu = 0; p.colsum = nullptr;
+  p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads; p.relu = 0; p.colsum = nullptr; p.col_off = 0;
   const int64_t nrt = (N + BM - 1) / BM;
   const int64_t nrt8 = (nrt + 7) / 8 * 8;        // row tiles rounded up to the XCD group size
   static const int n_cu = [] {
@@ -826,6 +829,38 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }();
   static const bool use_wreg = [] { const char* e = getenv("BGNN_GEMM_WREG"); return !e || atoi(e) != 0; }();
+  // Tail rows that need ONE table (the resident input halo of a partitioned graph: a halo row feeds destinations of one
+  // domain): two extra launches over the column range of that table -- half the MFMA work and half the writes for them.
+  // Outside the envelope below the tail rows simply get both tables like every other row.
+  if ((n_tail_t2s || n_tail_s2t) && use_wreg && n_heads == 1 && ldh % 64 == 0 && Din <= 128) {
+    const int64_t n_both = N - n_tail_t2s - n_tail_s2t;
+    const int nct = ldh % 256 == 0 ? 8 : ldh % 128 == 0 ? 4 : 2;
+    const int nw = nct == 2 ? 4 : 8;
+    const int bmw = 32 * (nw / nct);
+    static const bool bf3 = [] { const char* e = getenv("BGNN_GEMM_BF3"); return !e || atoi(e) != 0; }();
+    auto one_table = [&](int64_t r0, int64_t n, int table) {
+      if (n <= 0) return;
+      GemmParams q = p;
+      q.x = x + r0 * ldx; q.mask = mask + r0; q.N = n;
+      q.out[0][0] = h_s2t_0 + r0 * row_stride; q.out[0][1] = h_t2s_0 + r0 * row_stride;
+      q.col_off = table * (int)ldh; q.NC = (table + 1) * (int)ldh;
+      const int64_t ntiles = (n + bmw - 1) / bmw;
+      const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
+      const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), (unsigned)(ldh / (32 * nct)));
+#define BGNN_WREG1(DK, NCT, NW) do { if (bf3 && NCT >= 4) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, true, 0>), grid, dim3(64 * NW), 0, st, q); \
+                                      else hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, false, 0>), grid, dim3(64 * NW), 0, st, q); } while (0)
+#define BGNN_WREG1_DK(NCT, NW) do { if (Din <= 64) BGNN_WREG1(64, NCT, NW); else BGNN_WREG1(128, NCT, NW); } while (0)
+      if (nct == 2) BGNN_WREG1_DK(2, 4); else if (nct == 4) BGNN_WREG1_DK(4, 8); else BGNN_WREG1_DK(8, 8);
+#undef BGNN_WREG1_DK
+#undef BGNN_WREG1
+    };
+    one_table(n_both, n_tail_t2s, 1);
+    one_table(n_both + n_tail_t2s, n_tail_s2t, 0);
+    BGNN_LAUNCH_CHECK();
+    if (n_both == 0) return 0;
+    N = n_both;
+    p.N = n_both;
+  }
   if (use_wreg && NC % 64 == 0 && Din <= 128) {   // (Din = 256 needs 128 weight registers per lane and spills)
     // W-stationary persistent kernel: one 512-thread block per CU, column groups of 32*NCT in grid.y
     // NC <= 64: 4-wave blocks (2 column tiles x 2 row sub-tiles), two per CU; wider: 8-wave blocks, one per CU
@@ -878,10 +913,11 @@ extern "C" int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, in
                                                    int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
                                                    const float* gates, const float* gate_const_opt,
                                                    float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                                                   int64_t ldh, int64_t row_stride, float* small_ws, void* stream) {
+                                                   int64_t ldh, int64_t row_stride, int64_t n_tail_t2s, int64_t n_tail_s2t,
+                                                   float* small_ws, void* stream) {
   if (!sums) return BGNN_E_NULL;
   return transform_impl(x, N, Din, ldx, mask, nullptr, sums, n_heads, D, Wp, bias_p, gates, gate_const_opt,
-                        h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream);
+                        h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream, n_tail_t2s, n_tail_s2t);
 }
 
 extern "C" int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,

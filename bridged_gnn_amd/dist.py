@@ -16,12 +16,15 @@ The reference is single-process / single-device; this is new 
          (so each table sees the halo as its own continuation).  Full mesh: every peer pair uses its
          own xGMI link, no ring;
       4. fused aggregation in two parts: every row's LOCAL-source edges are aggregated WHILE the halo is in
-         flight (rows with remote in-neighbours park their online-softmax state: (max, sum) + raw accumulator),
-         the remote-source edges of those rows after it landed (`part` = 1 / 2 of the aggregation ABI);
+         flight in ONE launch (interior rows are finished there, rows with remote in-neighbours park their
+         online-softmax state: (max, sum) + raw accumulator), the remote-source edges of those rows after it landed
+         (`part` = 1 / 2 and `park_begin` of the aggregation ABI);
       5. outputs stay partitioned; BN(eval)/ReLU/log_softmax are row-local.
   * `PartitionPlan` (pure numpy + torch index tensors, device agnostic) is the host logic and is what the
     world_size-2 gloo CPU tests exercise; `PartitionedKTGNN` is the GPU driver on top of ops.py.
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -100,6 +103,8 @@ class PartitionPlan:
         r_id, r_owner, r_table = r_id[order], r_owner[order], r_table[order]
         self.recv_splits = np.bincount(r_owner, minlength=world).astype(np.int64).tolist()
         self.n_halo = int(r_id.shape[0])
+        self.halo_global = r_id.astype(np.int64)                 # global node id of every halo slot (a node needed from
+        self.halo_mask = mask[r_id]                              # both tables holds two slots) and its domain
         self.n_halo_by_table = [int((r_table == 0).sum()), int((r_table == 1).sum())]
         halo_pos = [np.full(N, -1, dtype=np.int64), np.full(N, -1, dtype=np.int64)]
         pos = np.arange(r_id.shape[0], dtype=np.int64)
@@ -112,6 +117,7 @@ class PartitionPlan:
         self.send_splits = np.bincount(s_needer, minlength=world).astype(np.int64).tolist()
         # index into the [h_s2t local | h_t2s local] region: h_t2s (table 0) rows live at n_local + r
         self.send_rows = g2l[s_id] + np.where(s_table == 0, self.n_local, 0)
+        self.send_rows_local = g2l[s_id]                         # the same rows as plain local row numbers (input features)
         # ---- local CSR (stable: input order inside a row, self loop last) ---------------------------
         keep = o_dst == rank
         ls, ld, lt = src[keep], dst[keep], table[keep]
@@ -121,6 +127,16 @@ class PartitionPlan:
         assert (lcol >= 0).all()
         order = np.argsort(lrow, kind="stable")
         self.col = lcol[order].astype(np.int32)
+        # "extended" numbering for a conv whose halo INPUT rows are resident (two separate tables of n_local + n_halo
+        # rows each, halo slot p at row n_local + p of the table that needs it)
+        # ... with the slots regrouped by table (h_t2s-only rows, then h_s2t-only rows) so that the transform can give
+        # each group just the table it is read from (`tail_single`)
+        self.halo_ext_perm = np.concatenate([np.nonzero(r_table == 0)[0], np.nonzero(r_table == 1)[0]])   # ext order -> slot
+        ext_pos = np.empty(max(self.n_halo, 1), dtype=np.int64)
+        ext_pos[self.halo_ext_perm] = np.arange(self.n_halo)
+        slot = np.where(lt == 0, halo_pos[0][ls], halo_pos[1][ls])
+        lcol_ext = np.where(owner[ls] == rank, g2l[ls], self.n_local + ext_pos[np.maximum(slot, 0)])
+        self.col_ext = lcol_ext[order].astype(np.int32)
         rp = np.zeros(self.n_local + 1, dtype=np.int64)
         np.add.at(rp, lrow + 1, 1)
         self.rowptr = np.cumsum(rp).astype(np.int32)
@@ -163,7 +179,11 @@ class HaloExchange:
     def start(self, big):
         """big = [h_s2t local | h_t2s local | halo] ([2*n_local + n_halo, ld]); the local rows must be final."""
         p = self.plan
-        send = big.index_select(0, self.send_rows)                   # [sum(send_splits), ld]
+        if big.is_cuda and big.dtype == torch.float32 and big.shape[1] % 4 == 0 and big.stride(1) == 1:
+            from . import ops
+            send = ops.gather_rows(big, self.send_rows)              # [sum(send_splits), ld]
+        else:                                                        # host tensors (gloo tests of the host logic)
+            send = big.index_select(0, self.send_rows)
         recv = big[2 * p.n_local: 2 * p.n_local + p.n_halo]
         self._keep = send
         self._work = None
@@ -183,13 +203,38 @@ class HaloExchange:
             self._work.wait()
         self._work, self._keep = None, None
 
+    def exchange_rows(self, rows):
+        """rows [sum(send_splits), ld] (already in send order) -> [n_halo, ld] in halo order; blocking.  Used once per
+        version of the input features (`PartitionedKTGNN._input_ext`), not per forward."""
+        p = self.plan
+        recv = torch.empty(p.n_halo, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        if p.world == 1 and not self.always:
+            return recv
+        if self.host_staging:
+            r_host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r_host, rows.cpu(), output_split_sizes=p.recv_splits,
+                                   input_split_sizes=p.send_splits, group=self.group)
+            recv.copy_(r_host)
+            return recv
+        dist.all_to_all_single(recv, rows.contiguous(), output_split_sizes=p.recv_splits,
+                               input_split_sizes=p.send_splits, group=self.group)
+        return recv
+
 
 class PartitionedKTGNN:
     """Eval forward of `KTGNN_no_complement` (models/KTGNN.py:401-435) on rank-local rows."""
 
     def __init__(self, model, edge_index, central_mask, rank, world, device, owner=None, group=None,
-                 always_communicate=False):
+                 always_communicate=False, cache_input_halo=True):
         from . import ops
+        # cache_input_halo: the FIRST conv reads the graph's input features, which do not change between forwards (the
+        # reference trains 300 epochs on one `data.x`).  Their halo rows are fetched once per version of x (same send
+        # lists, same all_to_all) and kept next to the local rows; every forward then transforms local + halo rows itself
+        # (weights do change) and needs no per-forward exchange of 512-byte rows for that conv -- on C4 / 8 ranks that
+        # exchange is ~100 MB per rank per forward, more than the rank's whole compute.  Later convs consume activations
+        # and keep the per-forward exchange.  False = exchange transformed rows for every conv.
+        self.cache_input_halo = bool(cache_input_halo)
+        self._x_ext_key, self._x_ext = None, None
         self.model, self.rank, self.world, self.device, self.group = model, rank, world, device, group
         self.always = always_communicate               # run the collectives even at world_size 1 (smoke-tests RCCL usage)
         plan = PartitionPlan(edge_index, central_mask, rank, world, owner=owner)
@@ -199,6 +244,10 @@ class PartitionedKTGNN:
         t = lambda a: torch.from_numpy(a).to(device)
         self.csr_L = ops.DstCSR(t(plan.rowptr_L), t(plan.col_L), None, int(plan.col_L.shape[0]), plan.n_local)
         self.csr_R = ops.DstCSR(t(plan.rowptr_R), t(plan.col_R), None, int(plan.col_R.shape[0]), plan.n_local)
+        self.csr_ext = ops.DstCSR(t(plan.rowptr), t(plan.col_ext), None, plan.local_num_edges, plan.n_local)
+        self.send_rows_local = t(plan.send_rows_local)
+        self.halo_ext_perm = t(plan.halo_ext_perm)
+        self.mask_ext_u8 = torch.cat((t(plan.mask_local), t(plan.halo_mask[plan.halo_ext_perm]))).to(torch.uint8).contiguous()
         self._states = {}
         self._state3 = None
         self.mask_local = torch.from_numpy(plan.mask_local).to(device)
@@ -229,10 +278,11 @@ class PartitionedKTGNN:
                          conv.a_f_s2t.weight.detach().reshape(-1).contiguous(), conv.out_channels, conv.negative_slope))
         kw = dict(n_dst=p.n_local, ep_scale=sc, ep_shift=sh, ep_relu=relu)
         for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
+            # ONE launch over the local-source edges of every row: interior rows (< n_interior) are finished,
+            # boundary rows park their state
             ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
-                                      row_begin=0, row_end=p.n_interior, colsum=colsum, **kw)
-            ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_L, self.mask_u8, D, slope, out=out,
-                                      row_begin=p.n_interior, row_end=p.n_local, state_ms=self._state(out), part=1, **kw)
+                                      row_begin=0, row_end=p.n_local, state_ms=self._state(out), part=1,
+                                      park_begin=p.n_interior, colsum=colsum, **kw)
         self.halo.wait()
         for (ht, hs, a1, a2, D, slope), out in zip(args, outs):
             ops.adaptedconv_aggregate(ht, hs, a1, a2, self.csr_R, self.mask_u8, D, slope, out=out,
@@ -247,6 +297,36 @@ class PartitionedKTGNN:
             st = torch.empty(self.plan.n_local, 2, dtype=torch.float32, device=self.device)
             self._states = {**self._states, key: st} if len(self._states) < 8 else {key: st}
         return st
+
+    def _input_ext(self, x):
+        """[x local rows ; x halo rows] (columns padded to a multiple of 4) for the current version of the input features:
+        the halo is fetched on first use and again whenever x is another tensor object or was written in place."""
+        from .ktgnn import _pad_cols4
+        key = self._x_ext_key
+        if key is None or key[0]() is not x or key[1] != x._version:
+            xp = _pad_cols4(x)
+            halo = self.halo.exchange_rows(xp.index_select(0, self.send_rows_local))
+            self._x_ext = torch.cat((xp, halo.index_select(0, self.halo_ext_perm)))      # halo regrouped by table
+            self._x_ext_key = (weakref.ref(x), x._version)
+        return self._x_ext
+
+    def _conv_resident_halo(self, conv, x, epilogue=None, out_sums=None, arena=None):
+        """First conv with resident input halo: all-reduce of the domain sums, transform of local + halo rows, ONE
+        aggregation launch over the complete local CSR -- no per-forward row exchange."""
+        from . import ops
+        from .ktgnn import _pad_cols4
+        p = self.plan
+        xp = _pad_cols4(x)
+        sums = ops.domain_sums(xp, self.mask_u8, out=arena.take(2 * xp.shape[1] + 2) if arena is not None else None)
+        if self.world > 1 or self.always:
+            sums = self._all_reduce(sums)
+        h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums, tail_single=tuple(p.n_halo_by_table))
+        sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
+        out = ops.adaptedconv_aggregate(h_t2s, h_s2t, conv.a_f_t2s.weight.detach().reshape(-1).contiguous(),
+                                        conv.a_f_s2t.weight.detach().reshape(-1).contiguous(), self.csr_ext, self.mask_u8,
+                                        conv.out_channels, conv.negative_slope, n_dst=p.n_local,
+                                        ep_scale=sc, ep_shift=sh, ep_relu=relu, colsum=out_sums)
+        return out[:, : conv.out_channels], sums
 
     def _conv(self, conv, x, epilogue=None, sums=None, out_sums=None, arena=None):
         from . import ops
@@ -273,7 +353,9 @@ class PartitionedKTGNN:
     @torch.no_grad()
     def forward(self, x_local):
         """x_local = x[owned_global] (rank-local rows in plan order) -> (logp_base, logp_target,
-        logp_target_hat) for those rows."""
+        logp_target_hat) for those rows.  With `cache_input_halo` the halo rows of x are re-fetched whenever x_local is
+        a different tensor or was modified in place (`_version`); a captured HIP graph cannot see that check, so
+        re-capture after changing x."""
         import torch.nn.functional as F
         m = self.model
         if m.training:
@@ -295,9 +377,11 @@ class PartitionedKTGNN:
                     n_h = 2 * ops.pad4(conv.out_channels) + 2
                     both = arena.take(2 * n_h)
                     s_h = both[:n_h]
-                x, _ = self._conv(conv, x, epilogue=(sc, sh, True), out_sums=s_h, arena=arena)   # epilogue also sums the finished rows
+                run = self._conv_resident_halo if (ind == 0 and self.cache_input_halo) else self._conv
+                x, _ = run(conv, x, epilogue=(sc, sh, True), out_sums=s_h, arena=arena)   # epilogue also sums the finished rows
             else:
-                x, _ = self._conv(conv, x, arena=arena)
+                run = self._conv_resident_halo if (ind == 0 and self.cache_input_halo) else self._conv
+                x, _ = run(conv, x, arena=arena)
                 x = F.relu(x)
             x = x.contiguous()
         # the two classifier inputs (h and T(h)) are both row-local once the hidden conv is done: their domain
@@ -354,9 +438,7 @@ class PartitionedKTGNN:
         kw = dict(n_dst=p.n_local, out=out3, heads=3, log_softmax=fused)
         slope = m.clf_base.negative_slope
         ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_L, self.mask_u8, C, slope,
-                                  row_begin=0, row_end=p.n_interior, **kw)
-        ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_L, self.mask_u8, C, slope,
-                                  row_begin=p.n_interior, row_end=p.n_local, state_ms=st, part=1, **kw)
+                                  row_begin=0, row_end=p.n_local, state_ms=st, part=1, park_begin=p.n_interior, **kw)
         self.halo.wait()
         ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, self.csr_R, self.mask_u8, C, slope,
                                   row_begin=p.n_interior, row_end=p.n_local, state_ms=st, part=2, **kw)

@@ -254,7 +254,7 @@ class AdaptedConv(nn.Module):
             self._pack_key = key
         return self._pack
 
-    def transform(self, x, mask_u8, delta=None, sums=None, out=None, partner=None):
+    def transform(self, x, mask_u8, delta=None, sums=None, out=None, partner=None, tail_single=(0, 0)):
         """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]; with `partner` (a second conv on the SAME
         input) -> [(h_t2s, h_s2t), (h_t2s', h_s2t')] from one pass over x."""
         xp = _pad_cols4(x)
@@ -264,7 +264,7 @@ class AdaptedConv(nn.Module):
         # with `sums` the kernel that forms W.delta also forms delta (bgnn_adaptedconv_transform_sums_f32)
         res = ops.adaptedconv_transform(xp, mask_u8, delta, self.packed(din_pad, partner),
                                         out=out if (out is None or partner is not None) else [out],
-                                        sums=sums if delta is None else None)
+                                        sums=sums if delta is None else None, tail_single=tail_single)
         return res if partner is not None else res[0]
 
     def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None, colsum=None):

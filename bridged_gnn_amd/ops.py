@@ -1,12 +1,14 @@
 """Tensor-level wrappers over the C ABI (one Python function per entry point of include/bgnn.h).
 Every function takes/returns CUDA(HIP) tensors on the current device and launches on torch's
 current stream.  No CPU path exists: host tensors raise."""
+import os
+
 import torch
 
 from . import _lib as L
 
 __all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "gram", "gram_supported", "rowdot",
-           "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "pad4"]
+           "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "gather_rows", "pad4"]
 
 
 def pad4(n):
@@ -173,11 +175,12 @@ def pack_transform_heads(heads, din_pad):
     return Wp, bp, gates, D, ldh, gconst
 
 
-def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None):
+def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None, tail_single=(0, 0)):
     """One pass over x -> per head (h_t2s, h_s2t) as [N, ldh] tensors (ldh = pad4(D); columns >= D are
     zero).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
     (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows).  With `delta=None` the domain
-    `sums` ([2*Din+2] float64) are consumed directly (same delta, one launch less)."""
+    `sums` ([2*Din+2] float64) are consumed directly (same delta, one launch less).  `tail_single=(n_t2s, n_s2t)`
+    (sums form only): the last n_t2s + n_s2t rows need only h_t2s / only h_s2t; their other table may stay unwritten."""
     lib = L.lib()
     Wp, bp, gates, D, ldh, gconst = packed
     H = gates.shape[0]
@@ -197,14 +200,20 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None):
         fn, first, name = lib.bgnn_adaptedconv_transform_sums_f32, sums, "bgnn_adaptedconv_transform_sums_f32"
     else:
         fn, first, name = lib.bgnn_adaptedconv_transform_f32, delta, "bgnn_adaptedconv_transform_f32"
+    tail = (int(tail_single[0]), int(tail_single[1])) if delta is None else ()
+    if delta is not None and tuple(tail_single) != (0, 0):
+        raise ValueError("tail_single needs the sums form of the transform")
     rc = fn(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(first), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates), L.ptr(gconst),
-            L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride,
+            L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride, *tail,
             L.ptr(small), L.stream())
     L.check(rc, name)
     return out
 
 
 _TILE_QUEUES = {}
+# second-part launches (a boundary row's two or three remote-source edges) run without the tile queue: nothing to keep
+# L2-resident there, and the claims' latency is most of such a short row's time (0.67 -> 0.64 ms per rank-sized forward)
+_P2_STATIC = os.environ.get("BGNN_P2_STATIC", "1") != "0"
 
 
 def _tile_queue(dev):
@@ -212,7 +221,7 @@ def _tile_queue(dev):
     key = (torch.device(dev).index, L.raw_stream())
     q = _TILE_QUEUES.get(key)
     if q is None:
-        q = _TILE_QUEUES[key] = torch.zeros(8, dtype=torch.int32, device=dev)
+        q = _TILE_QUEUES[key] = torch.empty(8, dtype=torch.int32, device=dev)     # the C entry zeroes it on the stream per launch
     return q
 
 
@@ -223,8 +232,11 @@ def heads_log_softmax_supported(heads, D):
 
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
-                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None, log_softmax=False):
+                          row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None, log_softmax=False,
+                          park_begin=None):
     """-> out [n_dst, pad4(D)] (use out[:, :D]); optionally alpha [E'] in CSR order.
+    part=1: rows [row_begin, park_begin) are finished in this launch, rows [park_begin, row_end) parked for part=2
+    (default: all parked).
     `log_softmax` (interleaved narrow heads only, see `heads_log_softmax_supported`): the finished rows leave the kernel
     as log_softmax over each head's D classes (KTGNN.py:435).
     Only rows [row_begin, row_end) are computed (default: all n_dst rows).
@@ -245,8 +257,9 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
-        L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part), int(heads), L.ptr(colsum),
-        L.ptr(_tile_queue(dev)) if heads == 1 else None, L.stream())
+        L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part),
+        int(row_begin) if park_begin is None else int(park_begin), int(heads), L.ptr(colsum),
+        L.ptr(_tile_queue(dev)) if heads == 1 and not (part == 2 and _P2_STATIC) else None, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out
 
@@ -344,6 +357,19 @@ def topk_edges(idx, cand_base=0, query_base=0):
     out = torch.empty(2, Nq * k, dtype=torch.int64, device=idx.device)
     rc = L.lib().bgnn_topk_edges_i64(L.ptr(idx), Nq, k, int(cand_base), int(query_base), L.ptr(out), L.stream())
     L.check(rc, "bgnn_topk_edges_i64")
+    return out
+
+
+def gather_rows(src, idx, out=None):
+    """out[r] = src[idx[r]] for a 2-D float32 table with unit column stride and a row length that is a multiple of 4
+    (the halo send lists; `index_select` needs 44 us for 2e5 rows of 48 bytes, this kernel the time of the bytes)."""
+    n, w = int(idx.shape[0]), int(src.shape[1])
+    if out is None:
+        out = torch.empty(n, w, dtype=torch.float32, device=src.device)
+    assert src.dtype == torch.float32 and idx.dtype == torch.int64 and w % 4 == 0 and out.shape == (n, w)
+    rc = L.lib().bgnn_gather_rows_f32(L.ptr_rows(src), src.shape[0], src.stride(0), L.ptr(idx), n, w, L.ptr_rows(out),
+                                      out.stride(0), L.stream())
+    L.check(rc, "bgnn_gather_rows_f32")
     return out
 
 

@@ -102,13 +102,17 @@ int bgnn_adaptedconv_transform_f32(const float* x, int64_t N, int32_t Din, int64
                                    float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                                    int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
 /* Same transform taking the domain sums ([2*Din+2] doubles, after any all-reduce) instead of delta: the tiny
- * W.delta kernel forms delta with the arithmetic of bgnn_domain_delta_f32 (bit-identical), one launch less per conv. */
+ * W.delta kernel forms delta with the arithmetic of bgnn_domain_delta_f32 (bit-identical), one launch less per conv.
+ * n_tail_t2s / n_tail_s2t: the LAST n_tail_t2s + n_tail_s2t of the N rows (in that order) are rows whose consumer reads
+ * only h_t2s / only h_s2t -- the resident input halo of a partitioned graph (dist.py): for them the other table MAY be
+ * left unwritten (single-table launches inside the W-stationary kernel's envelope, both tables outside it). */
 int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
                                         const uint8_t* mask, const double* sums,
                                         int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
                                         const float* gates, const float* gate_const_opt,
                                         float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
-                                        int64_t ldh, int64_t row_stride, float* small_ws, void* stream);
+                                        int64_t ldh, int64_t row_stride, int64_t n_tail_t2s, int64_t n_tail_s2t,
+                                        float* small_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11-a13) fused GATv2 logits + per-destination softmax + weighted neighbour sum.
@@ -128,7 +132,10 @@ int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, 
  * alpha_opt ([E'] in CSR order) is optional (tests / backward).
  * Two-part rows (multi-GPU overlap): part = 1 visits a row's first edge list and parks the online-softmax state
  * ((max, sum) in state_ms_opt [rows][2], the raw accumulator in out); part = 2 resumes from it over a second
- * edge list (another rowptr/col pair) and finishes the row.  part = 0 is the ordinary single launch.
+ * edge list (another rowptr/col pair) and finishes the row.  part = 0 is the ordinary single launch.  In part = 1 the
+ * rows [row_begin, park_begin) have no second part and are finished right away (epilogue, colsum), rows
+ * [park_begin, row_end) are parked: one launch serves a rank's interior and boundary rows (park_begin = row_begin
+ * parks every row).
  * heads > 1 evaluates several convs that share the graph in ONE pass (KTGNN.py:432-434: clf_base / clf_target /
  * clf_target-hat): their tables are interleaved row-wise ([rows, heads*ldh], head h of node r at (r*heads+h)*ldh),
  * a_t2s / a_s2t are [heads][D], out is [rows, heads*ldo] likewise; the in-neighbour ids are read once for all heads.
@@ -143,7 +150,7 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
                                    int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
                                    float* out, int64_t ldo, float* alpha_opt,
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                   float* state_ms_opt, int part, int32_t heads, double* colsum_opt,
+                                   float* state_ms_opt, int part, int64_t park_begin, int32_t heads, double* colsum_opt,
                                    uint32_t* tile_queue_opt, void* stream);
 
 /*  backward of the aggregation above -- what autograd computes through
@@ -204,6 +211,12 @@ int bgnn_mlp_pair_topk_f32(const float* A_cand /*[Nc,H]*/, const float* B_query 
  * main_bridged_graph.py:61-63,:105-107.  edge_index_out is [2, Nq*k].                          */
 int bgnn_topk_edges_i64(const int64_t* idx, int64_t Nq, int32_t k, int64_t cand_base, int64_t query_base,
                         int64_t* edge_index_out, void* stream);
+
+/* Packs table rows for a halo send list (bridged_gnn_amd/dist.py; the reference is single-device):
+ * dst[r, :row_floats] = src[idx[r], :row_floats].  row_floats % 4 == 0, 16-B aligned tables with ld % 4 == 0; indices
+ * are clamped into [0, src_rows).  Narrow rows (the classifier stage's 48-byte rows) are what the library gather is slow at. */
+int bgnn_gather_rows_f32(const float* src, int64_t src_rows, int64_t ld_src, const int64_t* idx, int64_t n,
+                         int32_t row_floats, float* dst, int64_t ld_dst, void* stream);
 
 /* (a8) torch_geometric.utils.coalesce -- call sites main_bridged_graph.py:75,:113,:193.
  * key = row*num_nodes + col, ascending, duplicates dropped.  In place on [2,E] (row stride E);

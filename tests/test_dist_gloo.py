@@ -80,6 +80,24 @@ def test_plan_world4_simulated_exchange():
             assert np.array_equal(np.sort(full), np.sort(parts))
         got[p.owned_global] = _aggregate_big(p, bigs[r], a1, a2)
     assert np.array_equal(got, ref)          # same per-row arithmetic order -> bitwise equal
+    # resident-input-halo layout of the first conv: two tables of n_local + n_halo rows, halo slot s at row n_local + s
+    # of the table that needs it, filled from the slot's global id (what `exchange_rows` delivers)
+    got2 = np.zeros_like(ref)
+    for p in plans:
+        ids = np.concatenate([p.owned_global, p.halo_global[p.halo_ext_perm]])     # halo regrouped: t2s-only, then s2t-only
+        assert np.array_equal(p.halo_mask, mask[p.halo_global])
+        t2s_e, s2t_e = h_t2s[ids].copy(), h_s2t[ids].copy()
+        n0, n1 = p.n_halo_by_table
+        s2t_e[p.n_local: p.n_local + n0] = np.nan                                # tables a halo group does NOT need may
+        t2s_e[p.n_local + n0:] = np.nan                                          # stay unwritten: poison them
+        n = ids.shape[0]
+        rowptr = np.concatenate([p.rowptr, np.full(n - p.n_local, p.rowptr[-1], np.int32)])
+        m_ext = np.concatenate([p.mask_local, p.halo_mask[p.halo_ext_perm]])
+        got2[p.owned_global] = OC.adaptedconv_aggregate(t2s_e, s2t_e, a1, a2, rowptr, p.col_ext, m_ext)[: p.n_local]
+        # what the owners would send for the input features: plain local row numbers of the same send list
+        for q, pq in enumerate(plans):
+            assert np.array_equal(pq.owned_global[pq.send_rows_local], pq.owned_global[pq.send_rows % pq.n_local])
+    assert np.array_equal(got2, ref)
 
 
 def _worker(rank, world, port, q):
@@ -96,6 +114,11 @@ def _worker(rank, world, port, q):
         hx.wait()
         out = _aggregate_big(p, big.numpy(), a1, a2)
         ok = bool(np.array_equal(out, ref[p.owned_global]))
+        # input-feature halo (fetched once per version of x): owners send plain local rows, slots arrive in halo order
+        feat = np.random.default_rng(9).standard_normal((mask.shape[0], 8)).astype(np.float32)
+        mine = torch.from_numpy(feat[p.owned_global])
+        halo = hx.exchange_rows(mine.index_select(0, torch.from_numpy(p.send_rows_local)))
+        ok = ok and bool(np.array_equal(halo.numpy(), feat[p.halo_global]))
         # (1) of the per-conv protocol: per-domain sums are all-reducible
         x = np.random.default_rng(5).standard_normal((mask.shape[0], 6))
         loc = x[p.owned_global]

@@ -119,9 +119,18 @@ def _gloo_gpu_worker(rank, world, port, q):
         x = torch.randn(5000, 64, device=DEV, generator=g)
         with torch.no_grad():
             ref = m(Data(x=x, edge_index=_t(ei), central_mask=_t(mask)))[:3]
-        pk = PartitionedKTGNN(m, ei, mask, rank, world, DEV)
-        out = pk.forward(x[pk.owned_global])
-        ok = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out, ref))
+        ok = True
+        for cache in (True, False):              # resident input halo for the first conv / exchange for every conv
+            pk = PartitionedKTGNN(m, ei, mask, rank, world, DEV, cache_input_halo=cache)
+            xl = x[pk.owned_global].contiguous()
+            out = pk.forward(xl)
+            ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out, ref))
+            if cache:                            # an in-place update of the features must re-fetch their halo
+                xl.mul_(0.5)
+                with torch.no_grad():
+                    ref2 = m(Data(x=x * 0.5, edge_index=_t(ei), central_mask=_t(mask)))[:3]
+                out2 = pk.forward(xl)
+                ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out2, ref2))
         q.put((rank, bool(ok), pk.plan.summary()))
     finally:
         dist.destroy_process_group()

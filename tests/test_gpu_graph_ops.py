@@ -133,3 +133,15 @@ def test_training_entry_points_reject_shapes_outside_their_envelope():
                                                    p(x), 16, p(b), p(x), 16, p(o), p(o), p(b), p(b), p(ws), ws.numel(), None)
     assert rc == -2
 
+
+
+@pytest.mark.parametrize("w,ld", [(12, 12), (128, 128), (4, 8), (36, 40)])
+def test_gather_rows_matches_index_select(w, ld):
+    from bridged_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(w)
+    table = torch.randn(5000, ld, device=DEV, generator=g)[:, :w]          # row-strided view when ld > w
+    idx = torch.randint(0, 5000, (12345,), device=DEV, generator=g)
+    assert torch.equal(ops.gather_rows(table, idx), table.index_select(0, idx))
+    assert ops.gather_rows(table, idx[:0]).shape == (0, w)
+    with pytest.raises(RuntimeError):
+        ops.gather_rows(table.t().contiguous().t(), idx)                   # column-major view: no unit column stride

@@ -248,6 +248,33 @@ def test_heads_log_softmax_epilogue(C, heads):
                                   torch.randn(64, device=DEV), csr, m8, 64, 0.1, log_softmax=True)
 
 
+@pytest.mark.parametrize("din,D", [(128, 128), (64, 64), (100, 256), (36, 31)])
+def test_transform_tail_single_table(din, D):
+    """tail_single: the last rows get only the table their consumer reads (resident input halo of a partitioned graph);
+    those values equal the ordinary two-table transform, and outside the kernel's envelope (D=31) both are written."""
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.ktgnn import AdaptedConv, _as_u8, _pad_cols4
+    n, n0, n1 = 4000, 700, 1300
+    rng = np.random.default_rng(D)
+    mask = _as_u8(_t(rng.random(n) < 0.5))
+    x = _pad_cols4(_t(rng.standard_normal((n, din)).astype(np.float32)))
+    torch.manual_seed(2)
+    conv = AdaptedConv(din, D, root_weight=False).to(DEV).eval()
+    ld = ops.pad4(D)
+    with torch.no_grad():
+        sums = ops.domain_sums(x[: n - n0 - n1], mask[: n - n0 - n1])          # the means come from the local rows only
+        full = conv.transform(x, mask, sums=sums)
+        out = (torch.full((n, ld), 7.0, device=DEV), torch.full((n, ld), 7.0, device=DEV))
+        got = conv.transform(x, mask, sums=sums, out=out, tail_single=(n0, n1))
+    nb = n - n0 - n1
+    assert_close(got[0][: nb + n0].cpu().numpy(), full[0][: nb + n0].cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="h_t2s")
+    assert_close(got[1][:nb].cpu().numpy(), full[1][:nb].cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="h_s2t local")
+    assert_close(got[1][nb + n0:].cpu().numpy(), full[1][nb + n0:].cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="h_s2t tail")
+    if D % 64 == 0 and din <= 128:                 # inside the envelope the other table of a tail row is left alone
+        assert float((got[1][nb: nb + n0] - 7.0).abs().max()) == 0.0
+        assert float((got[0][nb + n0:] - 7.0).abs().max()) == 0.0
+
+
 def test_graph_replay_matches_eager():
     """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
     order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""
