@@ -234,6 +234,7 @@ class PartitionedKTGNN:
         # exchange is ~100 MB per rank per forward, more than the rank's whole compute.  Later convs consume activations
         # and keep the per-forward exchange.  False = exchange transformed rows for every conv.
         self.cache_input_halo = bool(cache_input_halo)
+        self.single_table_halo = False
         self._x_ext_key, self._x_ext = None, None
         self.model, self.rank, self.world, self.device, self.group = model, rank, world, device, group
         self.always = always_communicate               # run the collectives even at world_size 1 (smoke-tests RCCL usage)
@@ -320,7 +321,10 @@ class PartitionedKTGNN:
         sums = ops.domain_sums(xp, self.mask_u8, out=arena.take(2 * xp.shape[1] + 2) if arena is not None else None)
         if self.world > 1 or self.always:
             sums = self._all_reduce(sums)
-        h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums, tail_single=tuple(p.n_halo_by_table))
+        # (`tail_single=p.n_halo_by_table` would give each halo group only the table it is read from: 397 instead of
+        #  500 MB of traffic, but three launches -- 130 vs 123 us on a rank's share of C4, so one launch does both tables)
+        h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums,
+                                      tail_single=tuple(p.n_halo_by_table) if self.single_table_halo else (0, 0))
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
         out = ops.adaptedconv_aggregate(h_t2s, h_s2t, conv.a_f_t2s.weight.detach().reshape(-1).contiguous(),
                                         conv.a_f_s2t.weight.detach().reshape(-1).contiguous(), self.csr_ext, self.mask_u8,

@@ -20,7 +20,8 @@ model = KTGNN_no_complement(128, 2, 2, 128, use_bn=True, dim_share=128).to(dev).
 class FakeHalo(D.HaloExchange):
     def start(self, big):
         p = self.plan
-        send = big.index_select(0, self.send_rows)
+        from bridged_gnn_amd import ops
+        send = ops.gather_rows(big, self.send_rows)
         recv = big[2 * p.n_local: 2 * p.n_local + p.n_halo]
         k = min(send.shape[0], recv.shape[0])
         recv[:k].copy_(send[:k])                       # stand-in payload of the right size
