@@ -25,6 +25,8 @@ SIGNATURES = {
                                                _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "bgnn_adaptedconv_transform_sums_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
                                                     _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "bgnn_linear_narrow_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _P, _P, _P]),
+    "bgnn_narrow_transform_finish_f32": (_INT, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
     "bgnn_gram_f32": (_INT, [_P, _I64, _I32, _P, _I64, _I32, _I64, _P, _P, C.c_size_t, _P]),
     "bgnn_rowdot_f32": (_INT, [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _P]),

@@ -146,6 +146,10 @@ struct GemmParams {
   int32_t relu;         // plain-linear mode (transform_wreg_kernel<.., MODE = 1>): out = relu?(x W^T + b)
   double* colsum;       // plain-linear mode, optional [2*NC + 2]: per-domain column sums (+ node counts) of the output
   int32_t col_off;      // transform_wreg_kernel: the launch covers the packed columns [col_off, NC) (one table of a head)
+  // MODE 2 (linear -> narrow transform, the activation never reaches HBM): second-stage operand and raw output
+  const float* w2;      // [8][NC]: packed rows of the consumer conv (4 of W_t, 4 of W_s), zero padded
+  const float* g2;      // [2][2*NC]: its gate vectors (s2t, t2s), x-half first
+  float* raw;           // [N][12]: W_t.a (4) | W_s.a (4) | a.g_s2t | a.g_t2s | 0 | 0   for the activation row a
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
@@ -360,11 +364,32 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   __shared__ float pre[2][BMW][PRE_LD];
   constexpr int CT_LD = 36;                  // wave-private 32x32 output tile (+4 floats: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float ctile[NW][32 * CT_LD];
+  // MODE 2: per-tile reduction of the second stage's 10 outputs per row over the NCT column waves
+  constexpr int R2_LD = 12;
+  __shared__ __attribute__((aligned(16))) float red2[MODE == 2 ? NCT : 1][MODE == 2 ? BMW * R2_LD : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, clean waitcnt placement
   const int fr = lane & 31, fh = lane >> 5;
   const int ct = wave % NCT, rs = wave / NCT;
   const int col_base = p.col_off + blockIdx.y * (32 * NCT) + ct * 32;
+  // MODE 2 second stage: out2[o][row] = sum_c w2[o][c] * a[row][c] over this wave's 32 columns as 16 fp32 MFMAs whose B
+  // operands are the activation registers as they are (register 4q+j of lane (fr, fh) = column 8q+4fh+j of row fr, i.e.
+  // k-pair {8q+j, 8q+4+j}); the stationary A operand pairs the same way: w2r[4q+j] = w2[o = fr][col_base + 8q+4fh+j]
+  float w2r[MODE == 2 ? 16 : 1];
+  if constexpr (MODE == 2) {                 // host: gridDim.y == 1, NC == 32 * NCT
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = col_base + 8 * q + 4 * fh + j;
+        float v = 0.f;
+        if (fr < 8) v = p.w2[(int64_t)fr * p.NC + c];
+        else if (fr < 10) v = p.g2[(int64_t)(fr - 8) * 2 * p.NC + c];
+        w2r[4 * q + j] = v;
+      }
+    for (int t = tid; t < NCT * BMW * R2_LD; t += 64 * NW) (&red2[0][0])[t] = 0.f;   // (columns 10, 11 stay zero)
+    // (the first __syncthreads of the tile loop orders these writes before their first use)
+  }
   // (host guarantees (NC - col_off) % (32 * NCT) == 0: every wave owns a full column tile -- no per-wave branches in the tile loop,
   //  which keeps the compiler's s_waitcnt placement exact)
 
@@ -523,13 +548,30 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
 
   float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // MODE 1: column sums of the rows this lane stored
   float n_s = 0.f, n_t = 0.f;
+  // MODE 2: a finished tile's 12 floats per row leave through red2 (summed over the NCT column waves there)
+  auto flush2 = [&](int64_t tl) {
+    if constexpr (MODE == 2) {
+      if (tid < BMW * 3) {
+        const int row = tid / 3, ch = tid % 3;
+        float4 v = *reinterpret_cast<const float4*>(&red2[0][row * R2_LD + 4 * ch]);
+#pragma unroll
+        for (int w = 1; w < NCT; ++w) {
+          const float4 u = *reinterpret_cast<const float4*>(&red2[w][row * R2_LD + 4 * ch]);
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const int64_t r = tl * BMW + row;
+        if (r < p.N) *reinterpret_cast<float4*>(p.raw + r * 12 + 4 * ch) = v;
+      }
+    }
+  };
   const int64_t ntiles = (p.N + BMW - 1) / BMW, last = ntiles - 1;     // gridDim.x <= ntiles (host)
   int64_t tile = blockIdx.x;
   gload(tile);
   sstore(0);
   gload(min(tile + (int64_t)gridDim.x, last));
   __builtin_amdgcn_s_waitcnt(0x0F70);         // enter the loop with no load pending (see the comment before the epilogue)
-  for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {   // block-uniform trip count
+  int it = 0;
+  for (; tile < ntiles; ++it, tile += gridDim.x) {   // block-uniform trip count
     const int cur = it & 1;
     __syncthreads();                          // buffer `cur` is complete; nobody still reads buffer cur^1
     // tile it+1 goes registers -> LDS, tile it+2 starts flying; past the end the last tile is staged again (never read)
@@ -571,6 +613,8 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[0][kb], bm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpc[0][kb], bh, acc, 0, 0, 0);
     }
+    // (two independent accumulator chains -- a lone dependent bf16 chain issues at half rate -- measured no gain here:
+    //  the two waves of a SIMD already fill the matrix pipe)
     }
     }
     // The loads issued above landed during the MFMA phase; retiring them HERE (vmcnt(0), free) lets the next
@@ -582,6 +626,7 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
     const bool sdom = pr[MAXH * 2] != 0.f;
     float* cw = ctile[wave];
     float cf = 0.f;
+    float a2[MODE == 2 ? 16 : 1];            // the activation values of this lane (row fr, 16 columns)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // rank-1 coefficient (KTGNN.py:277-280): -gate_s2t on source rows (table 0), +gate_t2s on target rows (table 1)
@@ -595,14 +640,33 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       float4 o;
       o.x = fmaf(cf, wv[q].x, acc[4 * q] + bv[q].x);     o.y = fmaf(cf, wv[q].y, acc[4 * q + 1] + bv[q].y);
       o.z = fmaf(cf, wv[q].z, acc[4 * q + 2] + bv[q].z); o.w = fmaf(cf, wv[q].w, acc[4 * q + 3] + bv[q].w);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE >= 1) {
         if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       }
-      *reinterpret_cast<float4*>(&cw[fr * CT_LD + 8 * q + 4 * fh]) = o;
+      if constexpr (MODE == 2) { a2[4 * q] = o.x; a2[4 * q + 1] = o.y; a2[4 * q + 2] = o.z; a2[4 * q + 3] = o.w; }
+      *reinterpret_cast<float4*>(&cw[fr * CT_LD + 8 * q + 4 * fh]) = o;     // MODE 2: only the column sums read it back
+    }
+    if constexpr (MODE == 2) {
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[r], a2[r], acc2, 0, 0, 0);
+      // accumulator register i of lane (fr, fh) is output 8*(i/4) + 4*fh + i%4 of row fr: lane half 0 holds outputs
+      // 0..3 and 8..11 (8, 9 are the gate products), lane half 1 outputs 4..7
+      // every column wave leaves its partial sums in its own slot (plain stores: ds_add_f32 from the NCT waves into one
+      // slot cost 0.16 ms per 1M rows); the flush adds the slots
+      float* r2 = &red2[ct][(rs * 32 + fr) * R2_LD];
+      if (fh == 0) {
+        *reinterpret_cast<float4*>(r2) = make_float4(acc2[0], acc2[1], acc2[2], acc2[3]);
+        *reinterpret_cast<float2*>(r2 + 8) = make_float2(acc2[4], acc2[5]);
+      } else {
+        *reinterpret_cast<float4*>(r2 + 4) = make_float4(acc2[0], acc2[1], acc2[2], acc2[3]);
+      }
     }
     // ... then a wave-private LDS transpose so every store instruction writes 8 rows x 128 contiguous bytes (whole
     // cache lines); lane-per-row 16-byte stores scatter one instruction over 32 lines and cost 0.14 ms here
-    if (ocol != nullptr) {
+    if (MODE == 2 || ocol != nullptr) {
       const int64_t row0 = tile * BMW + rs * 32 + (lane >> 3);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -612,8 +676,8 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
         if (v.x == 12345.678f)
 #endif
         if (row < p.N) {
-          *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
-          if constexpr (MODE == 1) {
+          if constexpr (MODE != 2) *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
+          if constexpr (MODE >= 1) {
             if (p.colsum != nullptr) {            // per-lane fp32 partials (4 fixed columns, ~500 rows per lane and launch)
               if (pre[cur][rs * 32 + (lane >> 3) + 8 * i][MAXH * 2] != 0.f) { cs_s.x += v.x; cs_s.y += v.y; cs_s.z += v.z; cs_s.w += v.w; n_s += 1.f; }
               else { cs_t.x += v.x; cs_t.y += v.y; cs_t.z += v.z; cs_t.w += v.w; n_t += 1.f; }
@@ -623,8 +687,14 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       }
     }
     }
+    if constexpr (MODE == 2) {
+      // the tile's rows leave through red2 in the same iteration (a second barrier per tile; deferring the flush to the
+      // next iteration's top put a branch with stores in front of the staging and the compiler drained vmcnt there: 2x slower)
+      __syncthreads();
+      flush2(tile);
+    }
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MODE >= 1) {
     if (p.colsum != nullptr) {
       // lanes -> block (ds_add_f32) -> one hardware fp64 atomic per (block, column, domain)
       __shared__ float red[2][32 * NCT + 1];
@@ -950,6 +1020,95 @@ extern "C" int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t l
   if (nct == 2) BGNN_LIN_DK(2, 4, false); else if (nct == 4) BGNN_LIN_DK(4, 8, true); else BGNN_LIN_DK(8, 8, true);
 #undef BGNN_LIN_DK
 #undef BGNN_LIN
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ linear -> narrow AdaptedConv transform, fused
+// KTGNN_no_complement.forward :433 evaluates clf_target on clf_transformer(h).  With the transformer's last Linear
+// folded into the conv's weights (ktgnn.py: _composed_target_pack) the only thing between h and that conv's narrow
+// tables is a1 = relu(BN(Linear0(h))) -- 512 MB written and read again at C4 size.  Stage A keeps a1 in the MFMA
+// accumulators and leaves 12 floats per row: (W_t a1, W_s a1, a1.g_s2t, a1.g_t2s) plus the per-domain column sums of
+// a1; stage B (after the sums are complete / all-reduced) applies bias and the rank-1 domain shift exactly like the
+// transform kernels' epilogue (KTGNN.py:277-284 by linearity, see the file header).
+namespace {
+__global__ __launch_bounds__(256) void narrow_finish_kernel(const float* __restrict__ raw, int64_t N,
+                                                            const uint8_t* __restrict__ mask,
+                                                            const float* __restrict__ bias, const float* __restrict__ wd,
+                                                            const float* __restrict__ gc, float* __restrict__ out_s2t,
+                                                            float* __restrict__ out_t2s, int64_t row_stride) {
+  const float4 b0 = *reinterpret_cast<const float4*>(bias), b1 = *reinterpret_cast<const float4*>(bias + 4);
+  const float4 w0 = *reinterpret_cast<const float4*>(wd), w1 = *reinterpret_cast<const float4*>(wd + 4);
+  const float g0 = gc[0], g1 = gc[1];
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(raw + r * 12);
+    const float4 b = *reinterpret_cast<const float4*>(raw + r * 12 + 4);
+    const float2 pg = *reinterpret_cast<const float2*>(raw + r * 12 + 8);
+    const bool sdom = mask[r] != 0;
+    const float c0 = sdom ? -tanh_fast(pg.x + g0) : 0.f;      // -gate_s2t on source rows (table 0 = h_s2t)
+    const float c1 = sdom ? 0.f : tanh_fast(pg.y + g1);       // +gate_t2s on target rows (table 1 = h_t2s)
+    float4 o0, o1;
+    o0.x = fmaf(c0, w0.x, a.x + b0.x); o0.y = fmaf(c0, w0.y, a.y + b0.y);
+    o0.z = fmaf(c0, w0.z, a.z + b0.z); o0.w = fmaf(c0, w0.w, a.w + b0.w);
+    o1.x = fmaf(c1, w1.x, b.x + b1.x); o1.y = fmaf(c1, w1.y, b.y + b1.y);
+    o1.z = fmaf(c1, w1.z, b.z + b1.z); o1.w = fmaf(c1, w1.w, b.w + b1.w);
+    *reinterpret_cast<float4*>(out_s2t + r * row_stride) = o0;
+    *reinterpret_cast<float4*>(out_t2s + r * row_stride) = o1;
+  }
+}
+}  // namespace
+
+extern "C" int bgnn_linear_narrow_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W,
+                                                const float* bias, int32_t Dout, int relu, const uint8_t* mask,
+                                                double* colsum, const float* Wp2, const float* gates2,
+                                                float* raw, void* stream) {
+  if (!x || !W || !bias || !mask || !colsum || !Wp2 || !gates2 || !raw) return BGNN_E_NULL;
+  // one column group of the W-stationary kernel must hold the whole activation row
+  if (N < 0 || Din <= 0 || Din > 128 || (Din & 3) || (ldx & 3) || ldx < Din || (Dout != 64 && Dout != 128 && Dout != 256))
+    return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(W) || !bgnn_aligned16(bias) || !bgnn_aligned16(raw)) return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p{};
+  p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = W; p.bias = bias;
+  p.ldh = Dout; p.row_stride = Dout; p.NC = Dout; p.n_heads = 1; p.relu = relu ? 1 : 0; p.colsum = colsum;
+  p.w2 = Wp2; p.g2 = gates2; p.raw = raw;
+  static const int n_cu = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }();
+  const int nct = Dout == 256 ? 8 : Dout == 128 ? 4 : 2;
+  const int nw = nct == 2 ? 4 : 8;
+  const int bmw = 32 * (nw / nct);
+  const int64_t ntiles = (N + bmw - 1) / bmw;
+  const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
+  const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), 1u);
+#define BGNN_LIN2(DK, NCT, NW, BF) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, BF, 2>), grid, dim3(64 * NW), 0, st, p)
+#define BGNN_LIN2_DK(NCT, NW, BF) do { if (Din <= 64) BGNN_LIN2(64, NCT, NW, BF); else BGNN_LIN2(128, NCT, NW, BF); } while (0)
+  if (nct == 2) BGNN_LIN2_DK(2, 4, false); else if (nct == 4) BGNN_LIN2_DK(4, 8, true); else BGNN_LIN2_DK(8, 8, true);
+#undef BGNN_LIN2_DK
+#undef BGNN_LIN2
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, const uint8_t* mask, const double* sums,
+                                                int32_t Din, const float* Wp2, const float* bias2, const float* gates2,
+                                                const float* gate_const_opt, float* h_s2t, float* h_t2s,
+                                                int64_t row_stride, float* small_ws, void* stream) {
+  if (!raw || !mask || !sums || !Wp2 || !bias2 || !gates2 || !h_s2t || !h_t2s || !small_ws) return BGNN_E_NULL;
+  if (N < 0 || Din <= 0 || (Din & 3) || row_stride < 4 || (row_stride & 3)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(raw) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(h_t2s) || !bgnn_aligned16(bias2) ||
+      !bgnn_aligned16(small_ws)) return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  float* wd = small_ws;        // [8]
+  float* gc = small_ws + 8;    // [2]
+  hipLaunchKernelGGL(wd_kernel, dim3(3), dim3(256), 0, st, Wp2, 8, Din, (const float*)nullptr, sums, gates2, gate_const_opt, 1, wd, gc);
+  BGNN_LAUNCH_CHECK();
+  const int64_t nb = (N + 255) / 256;
+  hipLaunchKernelGGL(narrow_finish_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, st, raw, N, mask, bias2, wd, gc,
+                     h_s2t, h_t2s, row_stride);
   BGNN_LAUNCH_CHECK();
   return 0;
 }

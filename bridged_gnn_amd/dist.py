@@ -394,23 +394,35 @@ class PartitionedKTGNN:
         from .ktgnn import _pad_cols4
         # h1; T's last Linear is folded into the conv weights; its rank-local domain sums come out of the GEMM epilogue
         adjacent = both is not None and x.shape[1] == m.clf_transformer[0].weight.shape[0]
-        xt, s_t = m._transformer_hidden_eval(x, self.mask_u8, want_sums=True, sums_out=both[s_h.numel():] if adjacent else None)
-        xt = xt.contiguous()
+        m._fold_transformer()
+        dout, din = m._tf_w0.shape
+        pack_t = m._composed_target_pack(ops.pad4(dout))
+        raw = None
+        if (adjacent and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] == din
+                and ops.linear_narrow_supported(din, dout, pack_t)):
+            # fused pair: h1 never reaches HBM; stage A leaves 12 floats per row + the rank-local sums of h1, stage B
+            # (in _classifier_stage, after the all-reduce) finishes the narrow tables
+            s_t = both[s_h.numel():]
+            raw = ops.linear_narrow_transform(x, m._tf_w0, m._tf_b0, self.mask_u8, s_t, pack_t, relu=True)
+            xt = None
+        else:
+            xt, s_t = m._transformer_hidden_eval(x, self.mask_u8, want_sums=True, sums_out=both[s_h.numel():] if adjacent else None)
+            xt = xt.contiguous()
         if s_h is None:
             s_h = ops.domain_sums(_pad_cols4(x), self.mask_u8)
-        if s_t is None or s_t.numel() != 2 * _pad_cols4(xt).shape[1] + 2:
+        if raw is None and (s_t is None or s_t.numel() != 2 * _pad_cols4(xt).shape[1] + 2):
             s_t = ops.domain_sums(_pad_cols4(xt), self.mask_u8)
         if not (adjacent and s_t.data_ptr() == both[s_h.numel():].data_ptr()):
             both = torch.cat((s_h, s_t))
         if self.world > 1 or self.always:
             both = self._all_reduce(both)
         s_h, s_t = both[: s_h.numel()], both[s_h.numel():]
-        logp, fused = self._classifier_stage(x, xt, s_h, s_t)
+        logp, fused = self._classifier_stage(x, xt, s_h, s_t, raw=raw, pack_t=pack_t)
         if not fused:
             logp = F.log_softmax(logp, dim=2)                                    # one launch for the three heads
         return logp[:, 0], logp[:, 1], logp[:, 2]
 
-    def _classifier_stage(self, x, xt, s_h, s_t):
+    def _classifier_stage(self, x, xt, s_h, s_t, raw=None, pack_t=None):
         """clf_base(x), clf_target(x), clf_target(T(x)) (KTGNN.py:432-434; `xt` = hidden activation h1 of T, whose
         last Linear is folded into the packed weights) with ONE halo exchange: the six narrow
         tables are interleaved column-wise in one allocation (row = [base | target | target-hat] x pad4(C) floats),
@@ -423,8 +435,11 @@ class PartitionedKTGNN:
         big = torch.empty(2 * p.n_local + p.n_halo, 3 * ld, dtype=torch.float32, device=self.device)
         views = [(big[p.n_local:, j * ld:(j + 1) * ld], big[:, j * ld:(j + 1) * ld]) for j in range(3)]   # (h_t2s, h_s2t)
         m.clf_base.transform(x, self.mask_u8, sums=s_h, partner=m.clf_target, out=[views[0], views[1]])
-        xtp = _pad_cols4(xt)
-        ops.adaptedconv_transform(xtp, self.mask_u8, None, m._composed_target_pack(xtp.shape[1]), out=[views[2]], sums=s_t)
+        if raw is not None:                                          # stage B of the fused linear -> narrow transform
+            ops.narrow_transform_finish(raw, self.mask_u8, s_t, pack_t, views[2])
+        else:
+            xtp = _pad_cols4(xt)
+            ops.adaptedconv_transform(xtp, self.mask_u8, None, m._composed_target_pack(xtp.shape[1]), out=[views[2]], sums=s_t)
         self.halo.start(big)
         akey = (m.clf_base._versions(), m.clf_target._versions())
         if getattr(m, "_a3_key", None) != akey:                      # same cache as the single-GPU forward

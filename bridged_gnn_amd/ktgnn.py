@@ -13,6 +13,7 @@ whose backward is the HIP kernel `bgnn_adaptedconv_aggregate_bwd_f32`; the dense
 `torch.autograd.Function` (fused HIP forward, hand-derived backward = two library GEMMs + row reductions).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -429,10 +430,8 @@ class KTGNN_no_complement(nn.Module):
         self._arena = arena
         return (x, sums) if want_sums else x
 
-    def _transformer_hidden_eval(self, x, mask_u8=None, want_sums=False, sums_out=None):
-        """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded: BN(Wx+b) = (s*W)x + (s*b + t)).  Inside the
-        envelope of `ops.linear` the W-stationary MFMA kernel applies bias + ReLU and, with `want_sums`, accumulates the
-        per-domain column sums of h1 in its epilogue; other shapes go through the library GEMM."""
+    def _fold_transformer(self):
+        """eval BatchNorm of clf_transformer folded into its first Linear (re-folded when a parameter / buffer changes)."""
         l0, bn, _, l3 = self.clf_transformer
         key = tuple((p.data_ptr(), p._version) for p in self.clf_transformer.parameters()) + \
             (bn.running_mean._version, bn.running_var._version)
@@ -443,6 +442,12 @@ class KTGNN_no_complement(nn.Module):
             self._tf_b0 = (l0.bias.detach() * s + bn.bias.detach() - bn.running_mean * s).float().contiguous()
             self._tf_key = key
             self._tf_pack = None
+
+    def _transformer_hidden_eval(self, x, mask_u8=None, want_sums=False, sums_out=None):
+        """h1 = relu(BN(Linear0(x))) of clf_transformer (eval; BN folded: BN(Wx+b) = (s*W)x + (s*b + t)).  Inside the
+        envelope of `ops.linear` the W-stationary MFMA kernel applies bias + ReLU and, with `want_sums`, accumulates the
+        per-domain column sums of h1 in its epilogue; other shapes go through the library GEMM."""
+        self._fold_transformer()
         sums = None
         dout, din = self._tf_w0.shape
         if x.dtype == torch.float32 and x.stride(1) == 1 and ops.linear_supported(din, dout):
@@ -454,6 +459,31 @@ class KTGNN_no_complement(nn.Module):
         else:
             h1 = F.relu(torch.addmm(self._tf_b0, x, self._tf_w0t))
         return (h1, sums) if want_sums else h1
+
+    def _transformer_to_target_tables(self, x, mask_u8, out, arena=None, all_reduce=None, sums_out=None):
+        """clf_target on clf_transformer(x) (:433) -> its narrow (h_t2s, h_s2t) tables in `out`.  Inside the envelope of
+        the fused pair the hidden activation h1 = relu(BN(Linear0(x))) never reaches HBM (stage A: raw per-row products +
+        domain sums of h1; `all_reduce` hook for partitioned graphs; stage B: bias + domain shift).  Otherwise h1 is
+        materialised by `_transformer_hidden_eval` and goes through the ordinary transform."""
+        self._fold_transformer()
+        dout, din = self._tf_w0.shape
+        pack = self._composed_target_pack(ops.pad4(dout))
+        n_s = 2 * ops.pad4(dout) + 2
+        if sums_out is None:
+            sums_out = arena.take(n_s) if arena is not None else torch.zeros(n_s, dtype=torch.float64, device=x.device)
+        if (x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] == din and ops.linear_narrow_supported(din, dout, pack)
+                and os.environ.get("BGNN_FUSED_TARGET", "1") != "0"):
+            raw = ops.linear_narrow_transform(x, self._tf_w0, self._tf_b0, mask_u8, sums_out, pack, relu=True)
+            sums1 = all_reduce(sums_out) if all_reduce is not None else sums_out
+            ops.narrow_transform_finish(raw, mask_u8, sums1, pack, out)
+            return
+        h1, sums1 = self._transformer_hidden_eval(x, mask_u8, want_sums=True, sums_out=sums_out)
+        h1p = _pad_cols4(h1)
+        if sums1 is None:
+            sums1 = ops.domain_sums(h1p, mask_u8)
+        if all_reduce is not None:
+            sums1 = all_reduce(sums1)
+        ops.adaptedconv_transform(h1p, mask_u8, None, self._composed_target_pack(h1p.shape[1]), out=[out], sums=sums1)
 
     def _composed_target_pack(self, din_pad):
         """clf_target evaluated on x' = h1.W3^T + b3 without materialising x' (the last Linear of clf_transformer is
@@ -509,12 +539,7 @@ class KTGNN_no_complement(nn.Module):
             # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
             # h1 = relu(BN(Linear0(x))) is materialised
             arena = self._arena
-            h1, sums1 = self._transformer_hidden_eval(
-                x, mask_u8, want_sums=True, sums_out=arena.take(2 * x.shape[1] + 2) if arena is not None else None)
-            h1p = _pad_cols4(h1)
-            if sums1 is None:
-                sums1 = ops.domain_sums(h1p, mask_u8)
-            ops.adaptedconv_transform(h1p, mask_u8, None, self._composed_target_pack(h1p.shape[1]), out=[views[2]], sums=sums1)
+            self._transformer_to_target_tables(x, mask_u8, views[2], arena)
             akey = (self.clf_base._versions(), self.clf_target._versions())
             if getattr(self, "_a3_key", None) != akey:           # stacked attention vectors, re-packed when a weight changes
                 cs = (self.clf_base, self.clf_target, self.clf_target)

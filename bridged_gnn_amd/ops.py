@@ -7,7 +7,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "gram", "gram_supported", "rowdot",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "linear_narrow_supported", "linear_narrow_transform", "narrow_transform_finish", "gram", "gram_supported", "rowdot",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "gather_rows", "pad4"]
 
 
@@ -113,6 +113,44 @@ def linear(x, weight, bias, relu=False, mask_u8=None, colsum=None):
     rc = L.lib().bgnn_linear_f32(L.ptr_rows(x), N, din, x.stride(0), L.ptr(weight), L.ptr(bias), dout, 1 if relu else 0,
                                  L.ptr(mask_u8), L.ptr(colsum), L.ptr(out), dout, L.stream())
     L.check(rc, "bgnn_linear_f32")
+    return out
+
+
+def linear_narrow_supported(din, dout, packed):
+    """envelope of `linear_narrow_transform`: W-stationary kernel with the whole activation row in one column group, and a
+    consumer conv of one head with D <= 4."""
+    Wp, bp, gates, D, ldh, gconst = packed
+    return (din <= 128 and din % 4 == 0 and dout in (64, 128, 256) and gates.shape[0] == 1 and ldh == 4
+            and Wp.shape == (8, dout))
+
+
+def linear_narrow_transform(x, weight, bias, mask_u8, colsum, packed, relu=True):
+    """Stage A of the fused clf_transformer -> clf_target path (KTGNN.py:433): raw [N,12] per-row products of
+    a = relu?(x W^T + b) with the consumer conv's packed rows and gate vectors, `colsum` (zeroed float64 [2*Dout+2])
+    += the per-domain column sums of a.  The activation itself is never written."""
+    N, din = x.shape
+    dout = weight.shape[0]
+    Wp, bp, gates, D, ldh, gconst = packed
+    raw = torch.empty(N, 12, dtype=torch.float32, device=x.device)
+    rc = L.lib().bgnn_linear_narrow_transform_f32(L.ptr_rows(x), N, din, x.stride(0), L.ptr(weight), L.ptr(bias), dout,
+                                                  1 if relu else 0, L.ptr(mask_u8), L.ptr(colsum), L.ptr(Wp), L.ptr(gates),
+                                                  L.ptr(raw), L.stream())
+    L.check(rc, "bgnn_linear_narrow_transform_f32")
+    return raw
+
+
+def narrow_transform_finish(raw, mask_u8, sums, packed, out):
+    """Stage B: raw [N,12] + the (all-reduced) domain sums of the activation -> the conv's (h_t2s, h_s2t) rows in `out`
+    (two [>=N, 4] views with a common row stride)."""
+    Wp, bp, gates, D, ldh, gconst = packed
+    h_t2s, h_s2t = out
+    N = raw.shape[0]
+    assert h_t2s.stride(0) == h_s2t.stride(0) and sums.dtype == torch.float64 and sums.numel() == 2 * Wp.shape[1] + 2
+    small = torch.empty(16, dtype=torch.float32, device=raw.device)
+    rc = L.lib().bgnn_narrow_transform_finish_f32(L.ptr(raw), N, L.ptr(mask_u8), L.ptr(sums), Wp.shape[1], L.ptr(Wp), L.ptr(bp),
+                                                  L.ptr(gates), L.ptr(gconst), L.ptr_rows(h_s2t), L.ptr_rows(h_t2s),
+                                                  h_t2s.stride(0), L.ptr(small), L.stream())
+    L.check(rc, "bgnn_narrow_transform_finish_f32")
     return out
 
 

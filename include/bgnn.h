@@ -84,6 +84,22 @@ int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* 
 int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,
                     int32_t Dout, int relu, const uint8_t* mask_opt, double* colsum_opt,
                     float* out, int64_t ldo, void* stream);
+/* Fused pair for KTGNN_no_complement.forward :433 (clf_target on clf_transformer(h), eval): the activation
+ *   a = relu?(x W^T + bias) of the transformer's first Linear (+ folded BatchNorm) never reaches HBM.
+ *   bgnn_linear_narrow_transform_f32 (stage A) leaves raw[N][12] = (W_t a [4] | W_s a [4] | a.g_s2t | a.g_t2s | 0 | 0)
+ *   for the consumer conv's packed operands Wp2 [8][Dout] (4 rows of W_t, 4 of W_s, zero padded: D <= 4) and gates2
+ *   [2][2*Dout], and accumulates the per-domain column sums + counts of a into colsum [2*Dout+2] (caller zero-fills;
+ *   multi-GPU callers all-reduce it).  bgnn_narrow_transform_finish_f32 (stage B) turns raw into the conv's h_s2t /
+ *   h_t2s rows (4 floats each, row_stride apart) with bias and the rank-1 domain shift of :277-284.
+ *   Envelope of stage A: Din <= 128, Din % 4 == 0, Dout in {64, 128, 256} (else BGNN_E_SHAPE: use bgnn_linear_f32 +
+ *   the transform).  small_ws: 16 floats. */
+int bgnn_linear_narrow_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W,
+                                     const float* bias, int32_t Dout, int relu, const uint8_t* mask,
+                                     double* colsum, const float* Wp2, const float* gates2, float* raw, void* stream);
+int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, const uint8_t* mask, const double* sums,
+                                     int32_t Din, const float* Wp2, const float* bias2, const float* gates2,
+                                     const float* gate_const_opt, float* h_s2t, float* h_t2s, int64_t row_stride,
+                                     float* small_ws, void* stream);
 /* bgnn_gram_f32: out[a][b] = sum_i A[i][a] * B[i][b] for tall-skinny A [N,p], B [N,q] (p <= 288, q <= 128, both % 4 == 0).
  *   The training path's weight / gate gradients of the dense transform (KTGNN.py:275-284 under autograd) are
  *   [G_s2t | G_t2s | dgate]^T . x with the node count as the reduction dimension; one streaming pass, deterministic

@@ -275,6 +275,51 @@ def test_transform_tail_single_table(din, D):
         assert float((got[0][nb + n0:] - 7.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("hidden,C,n", [(128, 2, 5000), (64, 3, 3333), (128, 4, 70), (256, 2, 1500)])
+def test_fused_transformer_target_tables(hidden, C, n):
+    """bgnn_linear_narrow_transform_f32 + bgnn_narrow_transform_finish_f32 (clf_target on clf_transformer(h), :433, with
+    the hidden activation kept on chip) == materialised h1 -> ordinary transform; also the domain sums of h1."""
+    import os
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement, _as_u8
+    torch.manual_seed(hidden + C)
+    model = KTGNN_no_complement(32, C, 2, hidden, use_bn=True, dim_share=32).to(DEV).eval()
+    with torch.no_grad():                       # non-trivial BatchNorm statistics
+        bn = model.clf_transformer[1]
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(1, 0.2); bn.bias.normal_(0, 0.2)
+    rng = np.random.default_rng(n)
+    mask = _as_u8(_t(rng.random(n) < 0.45))
+    x = _t(rng.standard_normal((n, hidden)).astype(np.float32))
+    ld = ops.pad4(C)
+
+    def run(fused):
+        os.environ["BGNN_FUSED_TARGET"] = "1" if fused else "0"
+        t2s = torch.full((n, 3 * ld), 9.0, device=DEV); s2t = torch.full((n, 3 * ld), 9.0, device=DEV)
+        sums = torch.zeros(2 * hidden + 2, dtype=torch.float64, device=DEV)
+        with torch.no_grad():
+            model._transformer_to_target_tables(x, mask, (t2s[:, 2 * ld:], s2t[:, 2 * ld:]), sums_out=sums)
+        return t2s, s2t, sums
+    try:
+        a, b = run(True), run(False)
+    finally:
+        os.environ.pop("BGNN_FUSED_TARGET", None)
+    assert ops.linear_narrow_supported(hidden, hidden, model._composed_target_pack(hidden)) == (hidden <= 128)   # 256: fallback
+    assert_close(a[0][:, 2 * ld:].cpu().numpy(), b[0][:, 2 * ld:].cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="h_t2s")
+    assert_close(a[1][:, 2 * ld:].cpu().numpy(), b[1][:, 2 * ld:].cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="h_s2t")
+    assert_close(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="domain sums of h1")
+    assert float((a[0][:, : 2 * ld] - 9.0).abs().max()) == 0.0          # neighbours' columns of the interleaved tables untouched
+    if ld > C:
+        assert float(a[0][:, 2 * ld + C:].abs().max()) == 0.0 and float(a[1][:, 2 * ld + C:].abs().max()) == 0.0
+    # against the reference arithmetic: h1 in fp64, then the C oracle's transform of clf_target on T(x)
+    with torch.no_grad():
+        xt = model.clf_transformer.double()(x.double()).float()
+        model.clf_transformer.float()
+    prm = {k: v.cpu().numpy() for k, v in model.clf_target.state_dict().items()}
+    hs2t, ht2s = OC.adaptedconv_transform(xt.cpu().numpy(), mask.cpu().numpy().astype(bool), prm)
+    assert_close(a[0][:, 2 * ld: 2 * ld + C].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=4e-6, what="h_t2s vs oracle")
+    assert_close(a[1][:, 2 * ld: 2 * ld + C].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=4e-6, what="h_s2t vs oracle")
+
+
 def test_graph_replay_matches_eager():
     """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
     order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""
