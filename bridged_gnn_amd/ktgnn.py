@@ -14,6 +14,7 @@ whose backward is the HIP kernel `bgnn_adaptedconv_aggregate_bwd_f32`; the dense
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -82,8 +83,20 @@ class Linear(nn.Module):
         return F.linear(x, self.weight, self.bias)
 
 
+_U8_CACHE = [None, -1, None]          # (weakref of the bool mask, its _version, uint8 copy)
+
+
 def _as_u8(mask):
-    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+    """central_mask as uint8 (the kernels' domain flag).  The reference keeps one bool mask per graph for the whole run,
+    so the last conversion is cached against the tensor object and its in-place version (three 1M-element conversions
+    per forward otherwise)."""
+    if mask.dtype == torch.uint8:
+        return mask
+    ref, ver, u8 = _U8_CACHE
+    if ref is None or ref() is not mask or ver != mask._version:
+        u8 = mask.to(torch.uint8).contiguous()
+        _U8_CACHE[:] = [weakref.ref(mask), mask._version, u8]
+    return u8
 
 
 def bn_eval_affine(bn, cache_owner=None):
