@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-input-halo-cache", action="store_true",
                     help="N>1: exchange transformed rows for the first conv on every forward instead of keeping the halo rows "
                          "of the (static) input features resident and transforming them locally")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N>1 code path with several ranks sharing one GPU (payload staged through the host)")
     ap.add_argument("--graph-replay", action="store_true", help="(default behaviour now; kept for old command lines)")
     ap.add_argument("--no-graph-replay", action="store_true",
                     help="skip the HIP-graph phase: by default the forward (collectives included) is captured once after the "
@@ -151,6 +153,15 @@ def cpu_baseline(args):
             "sample": f"same generator at N={n} nodes / E'={E} edges (1/4 scale), 1 eval forward, median of 3: {t:.3f} s"}
 
 
+def max_over_ranks(vals, dev):
+    """MAX all-reduce of a few floats; on the host when the process group is gloo (the `--dist-backend gloo` rehearsal of
+    the N>1 code path with several ranks on one GPU: RCCL refuses two ranks per device)."""
+    on_host = torch.distributed.get_backend() == "gloo"
+    t = torch.tensor(list(vals), dtype=torch.float64, device="cpu" if on_host else dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
 def knn_bench(args, dev, rank=0, world=1):
     """C5: cosine kNN bridge.  N>1: query rows are sharded over the ranks (candidates replicated, no collective in
     the data path -- SURVEY 8(e)); the job time is the max over ranks."""
@@ -172,9 +183,7 @@ def knn_bench(args, dev, rank=0, world=1):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = max_over_ranks([dt], dev)[0]
         ts.append(dt)
     t = float(np.median(ts[1:]))
     pairs = float(n) * float(n)
@@ -219,21 +228,27 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
                 g.replay()
             barrier()
             gdt = time.perf_counter() - t0
-        res = torch.tensor([gdt, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
-        if use_dist:
-            torch.distributed.all_reduce(res, op=torch.distributed.ReduceOp.MAX)
-        gdt, bad = float(res[0].item()), float(res[1].item())
+        gdt, bad = max_over_ranks([gdt, 0.0 if ok else 1.0], dev) if use_dist else (gdt, 0.0 if ok else 1.0)
         graph_ms = gdt / args.steps * 1e3
         if bad:
             note = "replayed outputs differ from the eager outputs, eager result kept"
     except Exception as exc:                              # the eager measurement stands
         note = f"capture failed: {type(exc).__name__}: {str(exc)[:120]}"
     done.set()
+    if note is not None and note.startswith("capture failed"):
+        # this rank cannot know whether its peers captured: they may be waiting in a replayed collective (their own
+        # watchdogs end them).  Do not meet them at a barrier -- print the eager line and leave.
+        if out is not None:
+            out["graph_replay_ms_per_step"] = note
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            os._exit(0)
+        return False
     if out is None:
-        return
+        return True
     if note is not None:
         out["graph_replay_ms_per_step"] = note
-        return
+        return True
     out["graph_replay_ms_per_step"] = graph_ms
     if graph_ms < out["ms_per_step"]:
         out["ms_per_step"] = graph_ms
@@ -241,6 +256,7 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
         out["config"]["execution"] = ("HIP-graph replay: the whole forward (all launches" +
                                       (" and the RCCL collectives" if use_dist else "") +
                                       ") captured once, outputs checked against the eager forward, K replays timed")
+    return True
 
 
 def main():
@@ -251,6 +267,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
+    if args.dist_backend == "gloo":                     # rehearsal: ranks share the GPUs there are
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -258,7 +276,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from bridged_gnn_amd import ops
     from bridged_gnn_amd.data import Data
@@ -331,9 +352,7 @@ def main():
         dt = time.perf_counter() - t0
     timed_agg.on = False
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = max_over_ranks([dt], dev)[0]
     ms_step = dt / args.steps * 1e3
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
     agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
@@ -393,9 +412,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         out["eager_ms_per_step"] = ms_step
         out["config"]["execution"] = "eager launches"
+    printed = False
     if not args.no_graph_replay:
-        graph_phase(args, runner, barrier, use_dist, dev, rank, out, 4 * Eprime)
-    if rank == 0:
+        printed = not graph_phase(args, runner, barrier, use_dist, dev, rank, out, 4 * Eprime)
+    if rank == 0 and not printed:
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.barrier()
