@@ -39,3 +39,10 @@ for exp in [int(a) for a in sys.argv[1:]] or [0, 1]:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); call(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     print("GEMM_EXP", exp, "ms med", round(float(np.median(ts)), 3), "min", round(min(ts), 3), flush=True)
+    if exp == 20:           # cycle stamps of transform_wreg_kernel's tile loop, summed over waves and the 60 calls above
+        buf = (C.c_ulonglong * 8)()
+        torch.cuda.synchronize()
+        assert lib.bgnn_debug_wreg_counters(buf) == 0
+        tiles = max(int(buf[5]), 1)
+        names = ["barrier wait", "stage (sstore + gload issue)", "MFMA chain", "vmcnt(0) wait", "epilogue + stores"]
+        print("per wave and tile, s_memtime ticks:", {n: round(int(buf[i]) / tiles, 1) for i, n in enumerate(names)}, "tiles", tiles, flush=True)
