@@ -20,6 +20,8 @@ SIGNATURES = {
     "bgnn_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "bgnn_build_dst_csr": (_INT, [_P, _I64, _I64, _INT, _P, _P, _P, _P, _P, _SZ, _P]),
     "bgnn_domain_sums_f64": (_INT, [_P, _I64, _I32, _I64, _P, _P, _P]),
+    "bgnn_domain_sums_workspace_bytes": (_SZ, [_I32]),
+    "bgnn_domain_sums_ws_f64": (_INT, [_P, _I64, _I32, _I64, _P, _P, _P, _SZ, _P]),
     "bgnn_domain_delta_f32": (_INT, [_P, _I32, _P, _P]),
     "bgnn_adaptedconv_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
                                                _P, _P, _P, _P, _I64, _I64, _P, _P]),

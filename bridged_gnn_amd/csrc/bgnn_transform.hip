@@ -24,9 +24,13 @@ namespace {
 // fp64 atomic per (block, column, domain).  Device-scope fp64 atomics on the same 2*Din addresses retire at only
 // ~3 G/s (measured: +90 ns per block), so the launch is ONE 1024-thread block per CU rather than many small ones.
 constexpr int DS_NT = 1024;
+// `part` != nullptr: two-stage form -- block b leaves its [2*Din+2] partial sums in part[b] (plain stores) and
+// domain_sums_reduce_kernel adds the blocks up; nullptr: the blocks add into `sums` with fp64 atomics (256 blocks x 258
+// same-address atomics are a ~23 us tail, which is why that form wants few, long blocks)
 __global__ __launch_bounds__(DS_NT) void domain_sums_kernel(const float* __restrict__ x, int64_t N, int32_t Din,
                                                           int64_t ldx, const uint8_t* __restrict__ mask,
-                                                          double* __restrict__ sums) {
+                                                          double* __restrict__ sums, double* __restrict__ part) {
+  if (part != nullptr) sums = part + (int64_t)blockIdx.x * (2 * Din + 2);
   const int nc4 = Din >> 2;                       // Din % 4 == 0
   const int cw = nc4 < 256 ? nc4 : 256;           // column lanes
   const int rl = DS_NT / cw;                       // row lanes
@@ -73,8 +77,13 @@ __global__ __launch_bounds__(DS_NT) void domain_sums_kernel(const float* __restr
       for (int q = 1; q < rl; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { as[e] += sh[((q * 2 + 0) * cw + cl) * 4 + e]; at[e] += sh[((q * 2 + 1) * cw + cl) * 4 + e]; }
+      if (part != nullptr) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(&sums[c4 * 4 + e], as[e]); unsafeAtomicAdd(&sums[Din + c4 * 4 + e], at[e]); }  // hardware fp64 atomic add
+        for (int e = 0; e < 4; ++e) { sums[c4 * 4 + e] = as[e]; sums[Din + c4 * 4 + e] = at[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(&sums[c4 * 4 + e], as[e]); unsafeAtomicAdd(&sums[Din + c4 * 4 + e], at[e]); }  // hardware fp64 atomic add
+      }
     }
     __syncthreads();
   }
@@ -89,8 +98,22 @@ __global__ __launch_bounds__(DS_NT) void domain_sums_kernel(const float* __restr
   if (tid < 2) {
     double t = 0.0;
     for (int w = 0; w < DS_NT / 64; ++w) t += sh[2 * w + tid];
-    unsafeAtomicAdd(&sums[2 * Din + tid], t);
+    if (part != nullptr) sums[2 * Din + tid] = t; else unsafeAtomicAdd(&sums[2 * Din + tid], t);
   }
+}
+
+__global__ __launch_bounds__(256) void domain_sums_reduce_kernel(const double* __restrict__ part, int nblocks, int ncol,
+                                                                 double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // four independent load chains; fixed order: run-to-run identical
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    a0 += part[(int64_t)b * ncol + c]; a1 += part[(int64_t)(b + 1) * ncol + c];
+    a2 += part[(int64_t)(b + 2) * ncol + c]; a3 += part[(int64_t)(b + 3) * ncol + c];
+  }
+  for (; b < nblocks; ++b) a0 += part[(int64_t)b * ncol + c];
+  sums[c] += (a0 + a1) + (a2 + a3);
 }
 
 __global__ void domain_delta_kernel(const double* __restrict__ sums, int32_t Din, float* __restrict__ delta) {
@@ -864,13 +887,28 @@ __global__ __launch_bounds__(256) void transform_skinny_kernel(GemmParams p) {
 
 }  // namespace
 
-extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
-                                    double* sums_io, void* stream) {
+static int domain_sums_impl(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                            double* sums_io, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !mask || !sums_io) return BGNN_E_NULL;
   if (N < 0 || Din <= 0 || ldx < Din || (Din & 3) || (ldx & 3)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   const int nc4 = Din / 4, cw = nc4 < 256 ? nc4 : 256, rl = DS_NT / cw;
+  const int ncol = 2 * Din + 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (ws != nullptr) {
+    // two-stage: every CU streams (>= 256 rows per block), partials in ws, one small launch adds them up
+    if (ws_bytes < sizeof(double) * 256 * (size_t)ncol) return BGNN_E_WORKSPACE;
+    int64_t grid = (N + 255) / 256;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(DS_NT), sizeof(double) * rl * 2 * cw * 4, st,
+                       x, N, Din, ldx, mask, sums_io, (double*)ws);
+    BGNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(domain_sums_reduce_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st,
+                       (const double*)ws, (int)grid, ncol, sums_io);
+    BGNN_LAUNCH_CHECK();
+    return 0;
+  }
   // 2*Din device-scope fp64 atomics per block at ~3 G/s: a block must stream >= 2048 rows to amortise them (a rank's
   // share of a partitioned graph is small), and never more blocks than CUs
   static const int64_t rpb = [] { const char* e = getenv("BGNN_DS_ROWS"); return e ? atoll(e) : 2048ll; }();
@@ -878,10 +916,25 @@ extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int6
   static const int64_t gcap = [] { const char* e = getenv("BGNN_DS_GRID"); return e ? atoll(e) : 256ll; }();
   if (grid > gcap) grid = gcap;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(DS_NT), sizeof(double) * rl * 2 * cw * 4,
-                     (hipStream_t)stream, x, N, Din, ldx, mask, sums_io);
+  hipLaunchKernelGGL(domain_sums_kernel, dim3((unsigned)grid), dim3(DS_NT), sizeof(double) * rl * 2 * cw * 4, st,
+                     x, N, Din, ldx, mask, sums_io, (double*)nullptr);
   BGNN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                                    double* sums_io, void* stream) {
+  return domain_sums_impl(x, N, Din, ldx, mask, sums_io, nullptr, 0, stream);
+}
+
+extern "C" size_t bgnn_domain_sums_workspace_bytes(int32_t Din) {
+  return Din > 0 ? sizeof(double) * 256 * (size_t)(2 * Din + 2) : 0;
+}
+
+extern "C" int bgnn_domain_sums_ws_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                                       double* sums_io, void* ws, size_t ws_bytes, void* stream) {
+  if (!ws) return BGNN_E_NULL;
+  return domain_sums_impl(x, N, Din, ldx, mask, sums_io, ws, ws_bytes, stream);
 }
 
 extern "C" int bgnn_domain_delta_f32(const double* sums, int32_t Din, float* delta, void* stream) {

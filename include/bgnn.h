@@ -74,6 +74,13 @@ int bgnn_build_dst_csr(const int64_t* edge_index, int64_t E, int64_t N, int rewr
  * small_ws: n_heads*(2*ldh+2) floats of scratch (W.delta and the gates' delta halves).       */
 int bgnn_domain_sums_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
                          double* sums_io /*[2*Din+2]*/, void* stream);
+/* Two-stage form of bgnn_domain_sums_f64 (same result up to fp64 summation order, and run-to-run identical): every CU
+ * streams its share and leaves a partial row in ws (bgnn_domain_sums_workspace_bytes(Din) bytes, no initialisation
+ * needed), a second small launch adds the rows into sums_io -- no atomics.  Same speed as the one-launch form on MI355X
+ * (1M x 128: 0.11 ms either way); its point is determinism. */
+size_t bgnn_domain_sums_workspace_bytes(int32_t Din);
+int bgnn_domain_sums_ws_f64(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                            double* sums_io /*[2*Din+2]*/, void* ws, size_t ws_bytes, void* stream);
 int bgnn_domain_delta_f32(const double* sums /*[2*Din+2]*/, int32_t Din, float* delta, void* stream);
 /* bgnn_linear_f32: out = relu?(x W^T + bias) for the first Linear (+ folded eval BatchNorm + ReLU) of
  *   KTGNN_no_complement.clf_transformer (models/KTGNN.py:407-411, applied at :433), on the same W-stationary MFMA kernel

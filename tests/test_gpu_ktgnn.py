@@ -320,6 +320,32 @@ def test_fused_transformer_target_tables(hidden, C, n):
     assert_close(a[1][:, 2 * ld: 2 * ld + C].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=4e-6, what="h_s2t vs oracle")
 
 
+@pytest.mark.parametrize("n,din", [(1, 4), (257, 36), (5000, 128), (100_003, 300), (70_000, 64)])
+def test_domain_sums_two_stage(n, din):
+    """bgnn_domain_sums_ws_f64 (ops.domain_sums(deterministic=True)) vs numpy fp64 and vs the one-stage atomic entry; the two-stage
+    form has no atomics, so repeated calls are bit-identical."""
+    from bridged_gnn_amd import _lib as L, ops
+    from bridged_gnn_amd.ktgnn import _pad_cols4
+    rng = np.random.default_rng(n + din)
+    x_np = (rng.standard_normal((n, din)) * 3).astype(np.float32)
+    m_np = rng.random(n) < 0.37
+    x, m = _pad_cols4(_t(x_np)), _t(m_np).to(torch.uint8)
+    dp = x.shape[1]
+    a = ops.domain_sums(x, m, deterministic=True)
+    b = ops.domain_sums(x, m, deterministic=True)
+    assert torch.equal(a, b)
+    want = np.zeros(2 * dp + 2)
+    want[:din] = x_np[m_np].astype(np.float64).sum(0)
+    want[dp: dp + din] = x_np[~m_np].astype(np.float64).sum(0)
+    want[2 * dp], want[2 * dp + 1] = m_np.sum(), (~m_np).sum()
+    assert_close(a.cpu().numpy(), want, rtol=1e-12, atol_scale=1e-13, what="two-stage sums")
+    one = torch.zeros(2 * dp + 2, dtype=torch.float64, device=DEV)
+    L.check(L.lib().bgnn_domain_sums_f64(L.ptr(x), n, dp, x.stride(0), L.ptr(m), L.ptr(one), L.stream()), "one-stage")
+    assert_close(one.cpu().numpy(), want, rtol=1e-12, atol_scale=1e-13, what="one-stage sums")
+    acc = ops.domain_sums(x, m, out=a.clone(), deterministic=True)   # accumulates into a non-zero buffer like the atomic form
+    assert_close(acc.cpu().numpy(), 2 * want, rtol=1e-12, atol_scale=1e-13, what="accumulate")
+
+
 def test_graph_replay_matches_eager():
     """KTGNN_no_complement.graphed(): the HIP-graph replay of the eval forward equals the eager forward (up to the
     order of the fp64 atomics in the domain sums) and follows in-place updates of the input features."""
