@@ -149,8 +149,34 @@ def cpu_baseline(args):
         fwd()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
-    return {"value": 4 * E / t, "unit": "edges/s", "cores": OC.num_threads(), "kind": "port",
+    return {"value": 4 * E / t, "unit": "edges/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
             "sample": f"same generator at N={n} nodes / E'={E} edges (1/4 scale), 1 eval forward, median of 3: {t:.3f} s"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def knn_cpu_baseline(n, k=20, sample_queries=8192):
+    """The oracle's C port of the cosine kNN (OpenMP, exhaustive canonical scores + top-k) on a bounded sample of C5:
+    `sample_queries` query rows against all n candidates."""
+    from bridged_gnn_amd import synth
+    from oracle import oracle_c as OC
+    nq = min(sample_queries, n)
+    q = OC.l2_normalize_rows(synth.gaussian_embeddings(n, 128, seed=0)[:nq])
+    c = OC.l2_normalize_rows(synth.gaussian_embeddings(n, 128, seed=1))
+    OC.cosine_topk(q[:64], c, k)
+    t0 = time.perf_counter()
+    OC.cosine_topk(q, c, k)
+    t = time.perf_counter() - t0
+    return {"value": float(nq) * n / t, "unit": "pairs/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
+            "sample": f"{nq} of the {n} query rows against all {n} candidates, d=128 k={k}: {t:.2f} s"}
 
 
 def max_over_ranks(vals, dev):
@@ -418,6 +444,8 @@ def main():
             out["train"] = train
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
+            if knn is not None:
+                out["knn"]["cpu_baseline"] = knn_cpu_baseline(args.knn_n)
         out["eager_ms_per_step"] = ms_step
         out["config"]["execution"] = "eager launches"
     printed = False
