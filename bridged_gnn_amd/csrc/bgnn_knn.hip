@@ -655,29 +655,9 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
     // 2 x 768), staging 660, barrier wait 1350, shortlist upkeep 1670 (queueing 980, drains 690 of which compaction 520).
     // Negative results: the skewed schedule below and parking single passes in per-lane registers until the next drain
     // (12.5 ms).
-    // EXPERIMENT (-DKNN_SKEW, slower: 13.2 vs 11.8 ms).  Waves w and w + NW/2 share a SIMD; the second half does the
-    // upkeep of tile t-1 FIRST and scores tile t afterwards, so that in every barrier interval one wave of a SIMD feeds
-    // the matrix pipe while its partner has the VALU (bf16 MFMA and VALU do overlap across waves, fp32 MFMA does not:
-    // tools/micro/mfma_valu_overlap.hip) -- in the full kernel the upkeep's LDS traffic and scalar control flow, not
-    // VALU issue, set its length, and the skew only adds a tile of latency to the threshold updates.  (Skewing only the
-    // staging -- second wave scores first, stages afterwards -- is equally flat: 12.4 vs 11.7 ms.  Waves w and w+4 do share
-    // a SIMD: tools/micro/wave_simd_map.hip.)
-#ifdef KNN_SKEW
-    if (wave >= NW / 2) {
-      int cur = 0;
-      f32x16 accp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accp[r] = -INFINITY;
-      for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
-        __syncthreads();
-        if (ct + 1 < ct1) sstore(cur ^ 1);
-        if (ct + 2 < ct1) gload(ct + 2);
-        if (ct > ct0) offer(accp, ct - 1);
-        accp = score(cur);
-      }
-      offer(accp, ct1 - 1);
-    } else
-#endif
+    // Tried and removed: a skewed schedule in which the second wave of every SIMD (waves w and w + NW/2
+    // share one: tools/micro/wave_simd_map.hip) does the upkeep of tile t-1 before it scores tile t -- 13.2 vs 11.8 ms;
+    // skewing only the staging was equally flat.
     {
     int cur = 0;
     for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
@@ -706,106 +686,6 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
 #endif
 }
 
-// (EXPERIMENT, compiled in but only launched with -DKNN_PINGPONG: slower than the default on MI355X)
-// pass 1, cosine, "ping-pong" form: 8 waves per block (256 queries), one block per CU.  Waves w and w+4 share a
-// SIMD; the two halves of the block alternate roles every phase -- while one half runs its 64-MFMA chain on the
-// tile, the other half does the shortlist upkeep of its previous tile -- so the matrix pipe of every SIMD always has
-// exactly one wave feeding it and the VALU/LDS bookkeeping hides behind the partner's MFMAs (two independent
-// blocks per CU were observed to run their MFMA chains and their bookkeeping in lockstep instead: no overlap).
-//   phase 2t  : half A: MFMA(tile t)   | half B: offer(tile t-1)      | all: issue global loads of tile t+1
-//   phase 2t+1: half A: offer(tile t)  | half B: MFMA(tile t)         | all: store tile t+1 into the free LDS buffer
-template <int DK, int CAPV, int KPV>
-__global__ __launch_bounds__(512) void cosine_pass1_pp_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
-                                                              int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
-                                                              float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
-  typedef WaveTopK<CAPV, KPV> TK;
-  constexpr int D = DK * 8, LD = D + 4, NW = 8, QB = NW * QPW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* stage = reinterpret_cast<float*>(smem);                           // [2][CT][LD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool halfB = wave >= 4;
-  const int64_t ntiles = (Nc + CT - 1) / CT;
-  const int64_t nqb = (Nq + QB - 1) / QB;
-  const int64_t T = nqb * ntiles;
-  int64_t t = (int64_t)blockIdx.x * tpb;
-  const int64_t t_end = min(T, t + tpb);
-  TK tk;
-  tk.carve(smem + sizeof(float) * 2 * CT * LD + (size_t)wave * TK::BYTES);
-
-  constexpr int F4_PER_ROW = D / 4;
-  constexpr int NLD = (CT * F4_PER_ROW + 511) / 512;
-  float4 pre[NLD];
-  auto gload = [&](int64_t ct) {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int f = tid + 512 * j;
-      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      const int64_t gc = ct * CT + r;
-      pre[j] = (f < CT * F4_PER_ROW && gc < Nc) ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int f = tid + 512 * j;
-      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      if (f < CT * F4_PER_ROW) *reinterpret_cast<float4*>(&stage[(buf * CT + r) * LD + c4 * 4]) = pre[j];
-    }
-  };
-  const int fr = lane & 31, fh = lane >> 5;
-
-  while (t < t_end) {                               // block-uniform: one segment per query block touched
-    const int64_t qb = t / ntiles, ct0 = t % ntiles;
-    const int64_t nt = min(ntiles - ct0, t_end - t); // tiles of this segment
-    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
-    const int64_t q0 = qb * QB + wave * QPW;
-    tk.init(lane);
-    float4 bq[DK];
-    {
-      const int64_t gq = q0 + fr;
-#pragma unroll
-      for (int kb = 0; kb < DK; ++kb)
-        bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float tau = -INFINITY;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    __syncthreads();                                 // previous segment is done with both stage buffers
-    gload(ct0);
-    sstore(0);
-    __syncthreads();
-    for (int64_t ph = 0; ph <= 2 * nt; ++ph) {       // half B lags half A by one phase
-      const int64_t ti = ph >> 1;                    // tile index (relative) half A works on in an even phase
-      const bool odd = ph & 1;
-      // staging for everybody: even phase -> fetch tile ti+1; odd phase -> park it in the buffer nobody reads
-      if (!odd) { if (ti + 1 < nt) gload(ct0 + ti + 1); }
-      else      { if (ti + 1 < nt) sstore((int)((ti + 1) & 1)); }
-      // which tile (if any) does this wave multiply / offer in this phase?
-      const int64_t mt = halfB ? (odd ? ti : -1) : (odd ? -1 : ti);                 // MFMA tile
-      const int64_t ot = halfB ? (odd ? -1 : ti - 1) : (odd ? ti : -1);             // offer tile
-      if (mt >= 0 && mt < nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* arow = &stage[((int)(mt & 1) * CT + fr) * LD + fh * 4];
-#pragma unroll
-        for (int kb = 0; kb < DK; ++kb) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
-        }
-      }
-      if (ot >= 0 && ot < nt)
-        offer_tile(tk, acc, (int)((ct0 + ot) * CT), Nc, lane, tau, (ot % DRAIN_EVERY) == DRAIN_EVERY - 1);
-      __syncthreads();
-    }
-    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
-    t += nt;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // pass 1, mlp (Similar_v2 'mlp' in separable eval form, H = 128): fp32 VALU scoring, same shortlist.
@@ -1129,21 +1009,6 @@ static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-  // ping-pong form (8 waves, 256 queries per block, one block per CU) when its LDS footprint fits
-#ifdef KNN_PINGPONG   // measured 29.4 ms vs 24.6 ms for the two-independent-blocks form on C5: kept for experiments only
-  constexpr size_t sh_pp = sizeof(float) * 2 * CT * LD + 8 * WaveTopK<CAPV, KPV>::BYTES;
-  if (sh_pp <= 160 * 1024) {
-    auto kern = cosine_pass1_pp_kernel<DK, CAPV, KPV>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_pp);
-    if (attr != hipSuccess) return (int)attr;
-    const Pass1Plan pl = plan_pass1(Nq, Nc, prop.multiProcessorCount, 2 * QPB);
-    *nslots_out = pl.nslots;
-    if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)pl.nblocks), dim3(512), sh_pp, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
-    BGNN_LAUNCH_CHECK();
-    return 0;
-  }
-#endif
   static const int db_nw = [] { const char* e = getenv("BGNN_KNN_DB"); return e ? atoi(e) : 8; }();   // 0 = two-barrier 4-wave form
   if constexpr (BF3) {
     constexpr size_t sh8 = (size_t)2 * CPIECES * CT * D * 2 + 8 * WaveTopK<CAPV, KPV>::BYTES;
