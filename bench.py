@@ -391,7 +391,7 @@ def main():
         y = torch.randint(0, args.classes, (N,), device=dev, generator=gen)
         tm = torch.rand(N, device=dev, generator=gen) < 0.5
         cm = data.central_mask
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-3)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-3, fused=True)   # same update, one launch
 
         tmt = tm & ~cm
         w_b, w_t = tm.float() / tm.sum(), tmt.float() / tmt.sum()
