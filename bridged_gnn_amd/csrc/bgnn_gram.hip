@@ -191,6 +191,50 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
   }
 }
 
+// Backward of the dense transform, row-local part (ktgnn.py: _TransformFn.backward): one stream over x and over the two
+// incoming gradient tables replaces ~25 torch element-wise / copy launches per conv.  For row i (S = source domain):
+//   pre_g = x_i . gx[g] + gconst[g];  gam_g = tanh(pre_g);  c1 = S ? gam_0 : 0;  c2 = S ? 0 : gam_1
+//   dc_0 = G_s2t[i,:D] . wd[0][:D];  dc_1 = G_t2s[i,:D] . wd[1][D:2D]          (adjoints of the gates)
+//   dpre = (S ? dc_0 (1 - gam_0^2) : 0,  S ? 0 : dc_1 (1 - gam_1^2))
+//   Gall[i] = [G_s2t[i,:D] | G_t2s[i,:D] | dpre_0 dpre_1 | 0...]  (p = pad4(2D+2) columns);  side[i] = (c1, c2, 1, 0)
+// 32 lanes own a row (two rows per wave); element-wise indexing over D so that any D works.
+__global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int din,
+                                                                 const float* __restrict__ G_s2t, const float* __restrict__ G_t2s,
+                                                                 int64_t ldg, int D, const uint8_t* __restrict__ mask,
+                                                                 const float* __restrict__ gx, const float* __restrict__ gconst,
+                                                                 const float* __restrict__ wd, float* __restrict__ Gall, int p,
+                                                                 float* __restrict__ side) {
+  const int tid = threadIdx.x, l32 = tid & 31;
+  const float gc0 = gconst[0], gc1 = gconst[1];
+  const int64_t rows_per_pass = (int64_t)gridDim.x * 8;             // 8 rows per block and pass
+  for (int64_t r = (int64_t)blockIdx.x * 8 + (tid >> 5); r < N; r += rows_per_pass) {
+    float a0 = 0.f, a1 = 0.f, d0 = 0.f, d1 = 0.f;
+    for (int k = l32 * 4; k < din; k += 128) {                      // din % 4 == 0 (host)
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + k);
+      const float4 u = *reinterpret_cast<const float4*>(gx + k), v = *reinterpret_cast<const float4*>(gx + din + k);
+      a0 = fmaf(xv.x, u.x, a0); a0 = fmaf(xv.y, u.y, a0); a0 = fmaf(xv.z, u.z, a0); a0 = fmaf(xv.w, u.w, a0);
+      a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
+    }
+    float* go = Gall + r * p;
+    for (int c = l32; c < D; c += 32) {
+      const float g1 = G_s2t[r * ldg + c], g2 = G_t2s[r * ldg + c];
+      d0 = fmaf(g1, wd[c], d0);
+      d1 = fmaf(g2, wd[2 * D + D + c], d1);
+      go[c] = g1; go[D + c] = g2;
+    }
+    a0 = bgnn::group_sum<32>(a0); a1 = bgnn::group_sum<32>(a1);
+    d0 = bgnn::group_sum<32>(d0); d1 = bgnn::group_sum<32>(d1);
+    if (l32 == 0) {
+      const bool S = mask[r] != 0;
+      const float g0 = tanhf(a0 + gc0), g1 = tanhf(a1 + gc1);
+      go[2 * D] = S ? d0 * (1.f - g0 * g0) : 0.f;
+      go[2 * D + 1] = S ? 0.f : d1 * (1.f - g1 * g1);
+      for (int c = 2 * D + 2; c < p; ++c) go[c] = 0.f;
+      *reinterpret_cast<float4*>(side + r * 4) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
@@ -208,6 +252,22 @@ extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d
     case 3: hipLaunchKernelGGL(rowdot_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
     default: hipLaunchKernelGGL(rowdot_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, X, ldx, N, d, V, ldv, out); break;
   }
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t,
+                                           const float* G_t2s, int64_t ldg, int32_t D, const uint8_t* mask,
+                                           const float* gx, const float* gconst, const float* wd, float* Gall, int32_t p,
+                                           float* side, void* stream) {
+  if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !Gall || !side) return BGNN_E_NULL;
+  if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 2 || (p & 3)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || !bgnn_aligned16(side)) return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  int64_t grid = (N + 7) / 8;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(transform_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, din, G_s2t,
+                     G_t2s, ldg, D, mask, gx, gconst, wd, Gall, p, side);
   BGNN_LAUNCH_CHECK();
   return 0;
 }

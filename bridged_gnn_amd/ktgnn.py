@@ -185,23 +185,29 @@ class _TransformFn(torch.autograd.Function):
         fast = x.stride(1) == 1 and x.stride(0) % 4 == 0 and din % 4 == 0 and x.data_ptr() % 16 == 0 and din <= 128 and D <= 128
         # gate pre-activations: ONE stream over x for both gates (the library needs a 0.5 ms GEMV per vector, or a 2 ms
         # GEMM with a 16-row macro tile for the [N,Din]x[Din,2] product)
-        Gx = torch.stack((g1[:din], g2[:din]))                                   # [2, Din]
-        pre = (ops.rowdot(x, Gx) if fast else x @ Gx.t()) + torch.stack((dl @ g1[din:], dl @ g2[din:]))
-        gam = torch.tanh(pre)
-        zero = gam.new_zeros(())
-        c1 = torch.where(m, gam[:, 0], zero)                                     # gate_s2t on source rows
-        c2 = torch.where(m, zero, gam[:, 1])                                     # gate_t2s on target rows
-        G1, G2 = G_s2t[:, :D], G_t2s[:, :D]
-        # Gall = [G1 | G2 | dpre1 | dpre2 | 0-pad]: every N-reduction below is a Gram product with Gall
-        p = ops.pad4(2 * D + 2)
-        Gall = x.new_zeros(N, p)
-        Gall[:, :D], Gall[:, D:2 * D] = G1, G2
+        Gx = torch.stack((g1[:din], g2[:din])).contiguous()                      # [2, Din]
+        gconst = torch.stack((dl @ g1[din:], dl @ g2[din:]))
         wd = x.new_zeros(2, 2 * D)
         wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
-        dc = ops.rowdot(Gall[:, :2 * D], wd) if fast and (2 * D) % 4 == 0 else Gall[:, :2 * D] @ wd.t()   # adjoints of the gates
-        dpre = torch.where(torch.stack((m, ~m), dim=1), dc * (1 - gam * gam), zero)
-        Gall[:, 2 * D:2 * D + 2] = dpre
-        side = torch.stack((c1, c2, torch.ones_like(c1), torch.zeros_like(c1)), dim=1)   # [N, 4]
+        # Gall = [G1 | G2 | dpre1 | dpre2 | 0-pad]: every N-reduction below is a Gram product with Gall
+        p = ops.pad4(2 * D + 2)
+        if (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
+                and G_s2t.stride(0) == G_t2s.stride(0)):
+            # row-local part in ONE stream over x and the two gradient tables (gate values, their adjoints, Gall, side)
+            Gall, side = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd)
+        else:
+            pre = x @ Gx.t() + gconst
+            gam = torch.tanh(pre)
+            zero = gam.new_zeros(())
+            c1 = torch.where(m, gam[:, 0], zero)                                 # gate_s2t on source rows
+            c2 = torch.where(m, zero, gam[:, 1])                                 # gate_t2s on target rows
+            G1, G2 = G_s2t[:, :D], G_t2s[:, :D]
+            Gall = x.new_zeros(N, p)
+            Gall[:, :D], Gall[:, D:2 * D] = G1, G2
+            dc = Gall[:, :2 * D] @ wd.t()                                        # adjoints of the gates
+            dpre = torch.where(torch.stack((m, ~m), dim=1), dc * (1 - gam * gam), zero)
+            Gall[:, 2 * D:2 * D + 2] = dpre
+            side = torch.stack((c1, c2, torch.ones_like(c1), torch.zeros_like(c1)), dim=1)   # [N, 4]
         if fast and ops.gram_supported(p, din):
             dWall = ops.gram(Gall, x)                                            # [p, Din]  streaming Gram kernel
             ex = torch.cat([ops.gram(side, Gall[:, c0:min(c0 + 128, p)]) for c0 in range(0, p, 128)], dim=1).t()   # [p, 4]

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "linear_narrow_supported", "linear_narrow_transform", "narrow_transform_finish", "gram", "gram_supported", "rowdot",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "linear_narrow_supported", "linear_narrow_transform", "narrow_transform_finish", "gram", "gram_supported", "rowdot", "transform_bwd_prep",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "gather_rows", "pad4"]
 
 
@@ -166,6 +166,20 @@ def narrow_transform_finish(raw, mask_u8, sums, packed, out):
                                                   h_t2s.stride(0), L.ptr(small), L.stream())
     L.check(rc, "bgnn_narrow_transform_finish_f32")
     return out
+
+
+def transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, gx, gconst, wd):
+    """-> (Gall [N, pad4(2D+2)], side [N, 4]): the row-local part of the transform backward in one pass (see bgnn.h)."""
+    N, din = x.shape
+    p = pad4(2 * D + 2)
+    Gall = torch.empty(N, p, dtype=torch.float32, device=x.device)
+    side = torch.empty(N, 4, dtype=torch.float32, device=x.device)
+    assert G_s2t.stride(0) == G_t2s.stride(0) and G_s2t.stride(1) == 1 and G_t2s.stride(1) == 1
+    rc = L.lib().bgnn_transform_bwd_prep_f32(L.ptr_rows(x), x.stride(0), N, din, L.ptr_rows(G_s2t), L.ptr_rows(G_t2s),
+                                             G_s2t.stride(0), D, L.ptr(mask_u8), L.ptr(gx), L.ptr(gconst), L.ptr(wd),
+                                             L.ptr(Gall), p, L.ptr(side), L.stream())
+    L.check(rc, "bgnn_transform_bwd_prep_f32")
+    return Gall, side
 
 
 def gram_supported(p, q):

@@ -157,3 +157,34 @@ def test_training_steps_follow_the_autograd_oracle():
     for (k, v), (_, r) in zip(model.state_dict().items(), ref.m.state_dict().items()):
         if v.dtype.is_floating_point:
             assert torch.allclose(v.cpu(), r, rtol=2e-3, atol=2e-4), k
+
+
+@pytest.mark.parametrize("din,D,n", [(128, 128, 3000), (128, 2, 4099), (36, 7, 1234), (64, 31, 999), (256, 64, 500)])
+def test_transform_bwd_prep_matches_torch_formula(din, D, n):
+    """bgnn_transform_bwd_prep_f32 (one stream) == the element-wise torch chain it replaces in _TransformFn.backward."""
+    from bridged_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(din + D)
+    ld = ops.pad4(D)
+    x = torch.randn(n, din, device=DEV, generator=g)
+    G1 = torch.zeros(n, ld, device=DEV); G2 = torch.zeros(n, ld, device=DEV)
+    G1[:, :D] = torch.randn(n, D, device=DEV, generator=g); G2[:, :D] = torch.randn(n, D, device=DEV, generator=g)
+    m = torch.rand(n, device=DEV, generator=g) < 0.4
+    gx = torch.randn(2, din, device=DEV, generator=g) * 0.2
+    gconst = torch.randn(2, device=DEV, generator=g) * 0.3
+    wd = torch.zeros(2, 2 * D, device=DEV)
+    wd[0, :D] = torch.randn(D, device=DEV, generator=g); wd[1, D:] = torch.randn(D, device=DEV, generator=g)
+    Gall, side = ops.transform_bwd_prep(x, G1, G2, D, m.to(torch.uint8), gx, gconst, wd)
+    gam = torch.tanh(x.double() @ gx.double().t() + gconst.double())
+    zero = gam.new_zeros(())
+    want_side = torch.stack((torch.where(m, gam[:, 0], zero), torch.where(m, zero, gam[:, 1]),
+                             torch.ones_like(gam[:, 0]), torch.zeros_like(gam[:, 0])), dim=1)
+    cat = torch.cat((G1[:, :D], G2[:, :D]), dim=1).double()
+    dc = cat @ wd.double().t()
+    dpre = torch.where(torch.stack((m, ~m), dim=1), dc * (1 - gam * gam), zero)
+    p = ops.pad4(2 * D + 2)
+    want = torch.zeros(n, p, dtype=torch.float64, device=DEV)
+    want[:, :2 * D], want[:, 2 * D:2 * D + 2] = cat, dpre
+    assert Gall.shape == (n, p)
+    assert torch.equal(Gall[:, :2 * D].double(), cat)
+    assert torch.allclose(Gall.double(), want, rtol=1e-5, atol=1e-5 * float(dc.abs().max()))
+    assert torch.allclose(side.double(), want_side, rtol=1e-5, atol=2e-6)
