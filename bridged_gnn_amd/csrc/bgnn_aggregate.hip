@@ -49,7 +49,8 @@ struct AggParams {
   int mode;          // 0: one launch; 1: first part -> leave (m, s) in state_ms and the raw accumulator in out;
                      // 2: second part -> resume from them, then normalise + epilogue
   int64_t park_begin;  // mode 1: nodes below it have no second part and are finished (normalise + epilogue) right away
-  int tq_chunk;      // consecutive tiles per queue claim (AGG_TQ_CHUNK; 1 for launches of only a few tiles per block)
+  int tq_chunk;      // tiles per queue claim
+  int tq_interleave; // see agg_wide_kernel
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -319,6 +320,11 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   // ~11 M/s (90 ns each, measured), so one atomic per 8-row tile put a floor of 125k tiles x 90 ns / 8 queues = 1.4 ms
   // under the C4 launch -- the kernel took 1.45 ms for 1 to 42 in-edges per row alike.
   const int TQ_CHUNK = p.tq_chunk;
+  // p.tq_interleave: claim k of an XCD does not take TQ_CHUNK CONSECUTIVE tiles but tiles r, r+G, r+2G, .. of super-chunk
+  // s (k = s*G + r, G = blocks on this XCD): the blocks then sweep the same G-tile window together, phase by phase --
+  // one atomic per TQ_CHUNK tiles with the L2 footprint of single-tile claims
+  const int64_t G = tr.step;
+  const int64_t tstride = p.tq_interleave ? G : 1;
   int64_t tile = tr.begin - tr.step;
   int64_t chunk_left = 0;
   for (;;) {
@@ -327,16 +333,23 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
         __syncthreads();
         if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[blockIdx.x % 8], 1u);
         __syncthreads();
-        tile = xbase + (int64_t)dyn_tile * TQ_CHUNK;
+        if (p.tq_interleave) {
+          const int64_t k = dyn_tile, sc = k / G, r = k - sc * G;
+          tile = xbase + sc * (TQ_CHUNK * G) + r;
+        } else {
+          tile = xbase + (int64_t)dyn_tile * TQ_CHUNK;
+        }
         chunk_left = TQ_CHUNK;
+        if (tile >= tr.end) break;               // first tile of a claim beyond the range: so is every later claim
       } else {
-        tile += 1;
+        tile += tstride;
       }
       --chunk_left;
+      if (tile >= tr.end) { chunk_left = 0; continue; }   // (interleaved: a later phase of the last super-chunk)
     } else {
       tile += tr.step;
+      if (tile >= tr.end) break;
     }
-    if (tile >= tr.end) break;
     const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end * p.heads;
     const int64_t ic = rvalid ? i : p.row_begin * p.heads;
@@ -712,6 +725,8 @@ int launch_wide(const AggParams& p, hipStream_t st) {
   if (grid < 8) grid = 8;
   AggParams q = p;
   q.tq_chunk = tq_chunk_for(ntiles, grid);
+  static const int il = [] { const char* e = getenv("BGNN_AGG_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  q.tq_interleave = il;
   hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
