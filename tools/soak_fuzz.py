@@ -1,0 +1,20 @@
+"""Soak of the seeded parity fuzzers (aggregation, transform, cosine kNN vs the C oracle) over seeds the test suite does
+not use: `python tools/soak_fuzz.py [first_seed [count]]` on a GPU box.  Round 1: seeds 100..259, 0 failures."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.chdir(os.path.join(ROOT, "tests"))
+import pytest, importlib
+import test_gpu_ktgnn as T, test_gpu_knn as K
+bad = []
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+for seed in range(first, first + count):
+    for name, fn in (("agg", T.test_aggregate_fuzz_vs_c_oracle), ("tr", T.test_transform_fuzz_vs_c_oracle), ("knn", K.test_cosine_topk_fuzz_bit_exact)):
+        try:
+            fn(seed)
+        except pytest.skip.Exception:
+            pass
+        except BaseException as e:
+            bad.append((name, seed, str(e)[:200])); print("FAIL", name, seed, str(e)[:300], flush=True)
+print("soak done, failures:", len(bad))
