@@ -136,7 +136,7 @@ def _gloo_gpu_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_partitioned_forward_real_processes_sharing_the_gpu(world):
     """The whole partitioned driver (plan, transform into the per-conv allocation, exchange, interior/boundary launches)
     with REAL ranks.  RCCL refuses two ranks on one device, so the process group is gloo and the payload is staged through
