@@ -31,7 +31,7 @@ SIGNATURES = {
     "bgnn_narrow_transform_finish_f32": (_INT, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
     "bgnn_gram_f32": (_INT, [_P, _I64, _I32, _P, _I64, _I32, _I64, _P, _P, C.c_size_t, _P]),
-    "bgnn_transform_bwd_prep_f32": (_INT, [_P, _I64, _I64, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I32, _P, _P]),
+    "bgnn_transform_bwd_prep_f32": (_INT, [_P, _I64, _I64, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "bgnn_rowdot_f32": (_INT, [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "bgnn_linear_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _I64, _P]),
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,

@@ -196,16 +196,19 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 //   pre_g = x_i . gx[g] + gconst[g];  gam_g = tanh(pre_g);  c1 = S ? gam_0 : 0;  c2 = S ? 0 : gam_1
 //   dc_0 = G_s2t[i,:D] . wd[0][:D];  dc_1 = G_t2s[i,:D] . wd[1][D:2D]          (adjoints of the gates)
 //   dpre = (S ? dc_0 (1 - gam_0^2) : 0,  S ? 0 : dc_1 (1 - gam_1^2))
-//   Gall[i] = [G_s2t[i,:D] | G_t2s[i,:D] | dpre_0 dpre_1 | 0...]  (p = pad4(2D+2) columns);  side[i] = (c1, c2, 1, 0)
+//   Gall[i] = [G_s2t[i,:D] | G_t2s[i,:D] | dpre_0 dpre_1 | +-1/n_dom | 0...]  (p = pad4(2D+3) columns);  side[i] = (c1, c2, 1, 0)
 // 32 lanes own a row (two rows per wave); element-wise indexing over D so that any D works.
 __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int din,
                                                                  const float* __restrict__ G_s2t, const float* __restrict__ G_t2s,
                                                                  int64_t ldg, int D, const uint8_t* __restrict__ mask,
                                                                  const float* __restrict__ gx, const float* __restrict__ gconst,
-                                                                 const float* __restrict__ wd, float* __restrict__ Gall, int p,
-                                                                 float* __restrict__ side) {
+                                                                 const float* __restrict__ wd, const double* __restrict__ counts,
+                                                                 float* __restrict__ Gall, int p, float* __restrict__ side) {
   const int tid = threadIdx.x, l32 = tid & 31;
   const float gc0 = gconst[0], gc1 = gconst[1];
+  // column 2D+2 of Gall: d(delta)/d(x_i) = +1/n_S on source rows, -1/n_T on target rows -- the input gradient's term
+  // through the domain means is then one more rank of the Gall . Wcat product instead of an [N,Din] multiply + add
+  const float cS = (float)(1.0 / counts[0]), cT = (float)(-1.0 / counts[1]);
   const int64_t rows_per_pass = (int64_t)gridDim.x * 8;             // 8 rows per block and pass
   for (int64_t r = (int64_t)blockIdx.x * 8 + (tid >> 5); r < N; r += rows_per_pass) {
     float a0 = 0.f, a1 = 0.f, d0 = 0.f, d1 = 0.f;
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
       const float g0 = tanhf(a0 + gc0), g1 = tanhf(a1 + gc1);
       go[2 * D] = S ? d0 * (1.f - g0 * g0) : 0.f;
       go[2 * D + 1] = S ? 0.f : d1 * (1.f - g1 * g1);
-      for (int c = 2 * D + 2; c < p; ++c) go[c] = 0.f;
+      go[2 * D + 2] = S ? cS : cT;
+      for (int c = 2 * D + 3; c < p; ++c) go[c] = 0.f;
       *reinterpret_cast<float4*>(side + r * 4) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
     }
   }
@@ -258,16 +262,16 @@ extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d
 
 extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t,
                                            const float* G_t2s, int64_t ldg, int32_t D, const uint8_t* mask,
-                                           const float* gx, const float* gconst, const float* wd, float* Gall, int32_t p,
-                                           float* side, void* stream) {
-  if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !Gall || !side) return BGNN_E_NULL;
-  if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 2 || (p & 3)) return BGNN_E_SHAPE;
+                                           const float* gx, const float* gconst, const float* wd, const double* counts,
+                                           float* Gall, int32_t p, float* side, void* stream) {
+  if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !counts || !Gall || !side) return BGNN_E_NULL;
+  if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 3 || (p & 3)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || !bgnn_aligned16(side)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   int64_t grid = (N + 7) / 8;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(transform_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, din, G_s2t,
-                     G_t2s, ldg, D, mask, gx, gconst, wd, Gall, p, side);
+                     G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, side);
   BGNN_LAUNCH_CHECK();
   return 0;
 }

@@ -190,11 +190,13 @@ class _TransformFn(torch.autograd.Function):
         wd = x.new_zeros(2, 2 * D)
         wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
         # Gall = [G1 | G2 | dpre1 | dpre2 | 0-pad]: every N-reduction below is a Gram product with Gall
-        p = ops.pad4(2 * D + 2)
-        if (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
-                and G_s2t.stride(0) == G_t2s.stride(0)):
-            # row-local part in ONE stream over x and the two gradient tables (gate values, their adjoints, Gall, side)
-            Gall, side = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd)
+        fused_prep = (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
+                      and G_s2t.stride(0) == G_t2s.stride(0))
+        p = ops.pad4(2 * D + 3) if fused_prep else ops.pad4(2 * D + 2)
+        if fused_prep:
+            # row-local part in ONE stream over x and the two gradient tables (gate values, their adjoints, Gall, side);
+            # column 2D+2 of Gall = +1/n_S | -1/n_T carries the gradient through the domain means (see dX below)
+            Gall, side = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, sums[-2:].contiguous())
         else:
             pre = x @ Gx.t() + gconst
             gam = torch.tanh(pre)
@@ -224,11 +226,14 @@ class _TransformFn(torch.autograd.Function):
             Wcat = x.new_zeros(p, din)                                          # rows: W_t, W_s, g1_x, g2_x
             Wcat[:D], Wcat[D:2 * D], Wcat[2 * D], Wcat[2 * D + 1] = W_t, W_s, g1[:din], g2[:din]
             ddl = sp[0] * g1[din:] + sp[1] * g2[din:] - W_t.t() @ u1 + W_s.t() @ u2
+            if fused_prep:
+                Wcat[2 * D + 2] = ddl                                           # x Gall[:, 2D+2] = +-1/n: through the domain means
             if ops.linear_supported(p, din):
                 dX = ops.linear(Gall, Wcat.t().contiguous(), x.new_zeros(din))  # skinny K: the W-stationary MFMA kernel
             else:
                 dX = Gall @ Wcat
-            dX = dX + torch.where(m, 1.0 / n_s, -1.0 / n_t)[:, None] * ddl[None, :]   # through the domain means
+            if not fused_prep:
+                dX = dX + torch.where(m, 1.0 / n_s, -1.0 / n_t)[:, None] * ddl[None, :]   # through the domain means
         db_s = ex[D:2 * D, 2] if ctx.has_bias[0] else None
         db_t = ex[:D, 2] if ctx.has_bias[1] else None
         return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None

@@ -173,7 +173,8 @@ def test_transform_bwd_prep_matches_torch_formula(din, D, n):
     gconst = torch.randn(2, device=DEV, generator=g) * 0.3
     wd = torch.zeros(2, 2 * D, device=DEV)
     wd[0, :D] = torch.randn(D, device=DEV, generator=g); wd[1, D:] = torch.randn(D, device=DEV, generator=g)
-    Gall, side = ops.transform_bwd_prep(x, G1, G2, D, m.to(torch.uint8), gx, gconst, wd)
+    counts = torch.tensor([float(m.sum()), float((~m).sum())], dtype=torch.float64, device=DEV)
+    Gall, side = ops.transform_bwd_prep(x, G1, G2, D, m.to(torch.uint8), gx, gconst, wd, counts)
     gam = torch.tanh(x.double() @ gx.double().t() + gconst.double())
     zero = gam.new_zeros(())
     want_side = torch.stack((torch.where(m, gam[:, 0], zero), torch.where(m, zero, gam[:, 1]),
@@ -181,9 +182,10 @@ def test_transform_bwd_prep_matches_torch_formula(din, D, n):
     cat = torch.cat((G1[:, :D], G2[:, :D]), dim=1).double()
     dc = cat @ wd.double().t()
     dpre = torch.where(torch.stack((m, ~m), dim=1), dc * (1 - gam * gam), zero)
-    p = ops.pad4(2 * D + 2)
+    p = ops.pad4(2 * D + 3)
     want = torch.zeros(n, p, dtype=torch.float64, device=DEV)
     want[:, :2 * D], want[:, 2 * D:2 * D + 2] = cat, dpre
+    want[:, 2 * D + 2] = torch.where(m, 1.0 / counts[0], -1.0 / counts[1])
     assert Gall.shape == (n, p)
     assert torch.equal(Gall[:, :2 * D].double(), cat)
     assert torch.allclose(Gall.double(), want, rtol=1e-5, atol=1e-5 * float(dc.abs().max()))
