@@ -417,7 +417,7 @@ def main():
             step()
         torch.cuda.synchronize()
         train = {"ms_per_train_step": (time.perf_counter() - t0) / args.train_steps * 1e3, "steps": args.train_steps,
-                 "what": "train-mode forward + backward (HIP kernels: pull + atomic aggregation backward, Gram/row-dot transform backward) + Adam on C4"}
+                 "what": "train-mode forward + backward (HIP kernels: pull aggregation backward, prep / Gram / W-stationary transform backward) + fused Adam on C4"}
         model.eval()
     knn = knn_bench(args, dev, rank, world) if not args.no_knn else None     # every rank takes part when N > 1
     out = None
