@@ -46,3 +46,23 @@ for exp in [int(a) for a in sys.argv[1:]] or [0, 1]:
         tiles = max(int(buf[5]), 1)
         names = ["barrier wait", "stage (sstore + gload issue)", "MFMA chain", "vmcnt(0) wait", "epilogue + stores"]
         print("per wave and tile, s_memtime ticks:", {n: round(int(buf[i]) / tiles, 1) for i, n in enumerate(names)}, "tiles", tiles, flush=True)
+        # the same stamps for MODE 2 (bgnn_linear_narrow_transform_f32: 64-row tiles, 4 column waves x 2 row sub-tiles)
+        f2 = lib.bgnn_linear_narrow_transform_f32
+        f2.restype, f2.argtypes = _lib.SIGNATURES["bgnn_linear_narrow_transform_f32"]
+        W0 = torch.randn(128, 128, device=dev) * 0.1; b0 = torch.randn(128, device=dev)
+        hd = {"W_s": torch.randn(2, 128, device=dev) * 0.1, "W_t": torch.randn(2, 128, device=dev) * 0.1, "b_s": torch.randn(2, device=dev),
+              "b_t": torch.randn(2, device=dev), "g_s2t": torch.randn(256, device=dev) * 0.1, "g_t2s": torch.randn(256, device=dev) * 0.1}
+        Wp2, bp2, g2, _, _, _ = ops.pack_transform_heads([hd], 128)
+        raw = torch.empty(N, 12, device=dev); cs = torch.zeros(258, dtype=torch.float64, device=dev)
+        def call2():
+            rc = f2(x.data_ptr(), N, 128, 128, W0.data_ptr(), b0.data_ptr(), 128, 1, mask.data_ptr(), cs.data_ptr(), Wp2.data_ptr(), g2.data_ptr(), raw.data_ptr(), None)
+            assert rc == 0, rc
+        for _ in range(5): call2()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(20):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(); call2(); e_.record(); torch.cuda.synchronize(); ts.append(s_.elapsed_time(e_))
+        assert lib.bgnn_debug_wreg_counters(buf) == 0
+        tiles = max(int(buf[5]), 1)
+        print("MODE 2 ms med", round(float(np.median(ts)), 3), "per wave and tile:", {n: round(int(buf[i]) / tiles, 1) for i, n in enumerate(names)}, "tiles", tiles, flush=True)
