@@ -51,6 +51,7 @@ struct AggParams {
   int64_t park_begin;  // mode 1: nodes below it have no second part and are finished (normalise + epilogue) right away
   int tq_chunk;      // tiles per queue claim
   int tq_interleave; // see agg_wide_kernel
+  int xcd_segments;  // see agg_wide_kernel
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -325,6 +326,14 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   // one atomic per TQ_CHUNK tiles with the L2 footprint of single-tile claims
   const int64_t G = tr.step;
   const int64_t tstride = p.tq_interleave ? G : 1;
+  // XCD balance: a contiguous eighth of the rows per XCD hands the XCDs that own the high-degree domain (the bridged
+  // graph's target rows have ~3x the in-edges of its source rows) most of the edges while the others idle.  With
+  // p.xcd_segments = S > 1 the rows are cut into 8*S contiguous segments dealt round-robin to the XCDs: position j of
+  // an XCD's own sequence is tile (j / seg_len * 8 + xcd) * seg_len + j % seg_len -- still long contiguous runs per L2.
+  const int NSEG = p.xcd_segments > 1 ? p.xcd_segments : 1;
+  const int64_t per_x = (ntiles + 7) / 8, seg_len = (per_x + NSEG - 1) / NSEG;
+  const int64_t xend = NSEG > 1 ? xbase + (int64_t)NSEG * seg_len : tr.end;
+  const int xcd = blockIdx.x % 8;
   int64_t tile = tr.begin - tr.step;
   int64_t chunk_left = 0;
   for (;;) {
@@ -340,17 +349,23 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
           tile = xbase + (int64_t)dyn_tile * TQ_CHUNK;
         }
         chunk_left = TQ_CHUNK;
-        if (tile >= tr.end) break;               // first tile of a claim beyond the range: so is every later claim
+        if (tile >= xend) break;                 // first tile of a claim beyond the range: so is every later claim
       } else {
         tile += tstride;
       }
       --chunk_left;
-      if (tile >= tr.end) { chunk_left = 0; continue; }   // (interleaved: a later phase of the last super-chunk)
+      if (tile >= xend) { chunk_left = 0; continue; }     // (interleaved: a later phase of the last super-chunk)
     } else {
       tile += tr.step;
-      if (tile >= tr.end) break;
+      if (tile >= xend) break;
     }
-    const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
+    int64_t gt = tile;
+    if (NSEG > 1) {
+      const int64_t j = tile - xbase, sg = j / seg_len;
+      gt = (sg * 8 + xcd) * seg_len + (j - sg * seg_len);
+      if (gt >= ntiles) continue;                // padding of the last segments (block-uniform)
+    }
+    const int64_t i = p.row_begin * p.heads + gt * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end * p.heads;
     const int64_t ic = rvalid ? i : p.row_begin * p.heads;
     const int64_t node = ic / p.heads;
@@ -727,6 +742,8 @@ int launch_wide(const AggParams& p, hipStream_t st) {
   q.tq_chunk = tq_chunk_for(ntiles, grid);
   static const int il = [] { const char* e = getenv("BGNN_AGG_INTERLEAVE"); return e ? atoi(e) : 1; }();
   q.tq_interleave = il;
+  static const int nseg = [] { const char* e = getenv("BGNN_XCD_SEGMENTS"); return e ? atoi(e) : 8; }();
+  q.xcd_segments = nseg;
   hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
