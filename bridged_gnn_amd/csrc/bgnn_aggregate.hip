@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
   const bool fvalid = f0 < p.D;          // pad lanes (LF*4 > ldh) never touch memory
 
   const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);          // positions of this XCD's segment sequence (XCD balance)
   // per-block column sums of the finished rows (per domain) live in LDS so the hot loop keeps its register budget
   __shared__ float red[2][LF * 4 + 1];
   if (p.colsum != nullptr) {
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void agg_kernel(AggParams p) {
       tile += tr.step;
     }
     if (tile >= tr.end) break;
+    const int64_t gt = bgnn::xcd_tile_of(tile, ntiles);     // `tile` is a position in the XCD's sequence
+    if (gt < 0) continue;
     // virtual row = (destination node, head); heads == 1: virtual row == node
-    const int64_t i = p.row_begin * p.heads + tile * RPB + wave * GPW + g;
+    const int64_t i = p.row_begin * p.heads + gt * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end * p.heads;
     const int64_t ic = rvalid ? i : p.row_begin * p.heads;
     const int64_t node = ic / p.heads;
@@ -550,9 +552,11 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / EP, sub = lane % EP;
   const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);    // positions of this XCD's segment sequence (XCD balance)
   const int64_t rs = (int64_t)HEADS * p.ldh;         // floats between consecutive nodes of a table
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
     const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end;
     const int64_t ic = rvalid ? i : p.row_begin;

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(BwdParams p) {
   float accS[4] = {0.f, 0.f, 0.f, 0.f}, accT[4] = {0.f, 0.f, 0.f, 0.f};   // da partials per domain
 
   const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
     const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.row_end;
     const int64_t ic = rvalid ? i : p.row_begin;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
   const int f0c = fvalid ? f0 : 0;
   float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;          // da partials per domain
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
   __shared__ unsigned int dyn_tile;
   const int64_t xbase = tr.begin - (blockIdx.x / 8);
   constexpr int TQ_CHUNK = 4;                     // tiles per queue fetch (same-address atomics retire at ~11 M/s)
@@ -180,7 +182,9 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
     }
     --chunk_left;
     if (tile >= tr.end) break;
-    const int64_t i = tile * RPB + wave * GPW + g;
+    const int64_t gt = bgnn::xcd_tile_of(tile, ntiles);     // `tile` is a position in the XCD's sequence
+    if (gt < 0) continue;
+    const int64_t i = gt * RPB + wave * GPW + g;
     const bool rvalid = i < p.N;
     const int64_t ic = rvalid ? i : 0;
     const bool dom_s = p.mask[ic] != 0;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
     aT.x = p.a_s2t[f0]; aT.y = f0 + 1 < p.D ? p.a_s2t[f0 + 1] : 0.f; aT.z = f0 + 2 < p.D ? p.a_s2t[f0 + 2] : 0.f; aT.w = f0 + 3 < p.D ? p.a_s2t[f0 + 3] : 0.f;
   }
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
   __shared__ unsigned int dyn_tile;
   const int64_t xbase = tr.begin - (blockIdx.x / 8);
   constexpr int TQ_CHUNK = 4;
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
     }
     --chunk_left;
     if (tile >= tr.end) break;
-    const int64_t j = tile * RPB + wave * GPW + g;
+    const int64_t gt = bgnn::xcd_tile_of(tile, ntiles);     // `tile` is a position in the XCD's sequence
+    if (gt < 0) continue;
+    const int64_t j = gt * RPB + wave * GPW + g;
     const bool rvalid = j < p.N;
     const int64_t jc = rvalid ? j : 0;
     const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
@@ -358,8 +364,10 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_narrow_kernel(PullParams p) {
   const int g = lane / EP, sub = lane % EP;
   float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
     const int64_t i = tile * RPB + wave * GPW + g;
     const bool rvalid = i < p.N;
     const int64_t ic = rvalid ? i : 0;
@@ -423,8 +431,10 @@ __global__ __launch_bounds__(256) void agg_bwd_src_narrow_kernel(PullParams p) {
   aS.x = p.a_t2s[0]; aS.y = p.D > 1 ? p.a_t2s[1] : 0.f; aS.z = p.D > 2 ? p.a_t2s[2] : 0.f; aS.w = p.D > 3 ? p.a_t2s[3] : 0.f;
   aT.x = p.a_s2t[0]; aT.y = p.D > 1 ? p.a_s2t[1] : 0.f; aT.z = p.D > 2 ? p.a_s2t[2] : 0.f; aT.w = p.D > 3 ? p.a_s2t[3] : 0.f;
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
-  for (int64_t tile = tr.begin; tile < tr.end; tile += tr.step) {
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
     const int64_t j = tile * RPB + wave * GPW + g;
     const bool rvalid = j < p.N;
     const int64_t jc = rvalid ? j : 0;
