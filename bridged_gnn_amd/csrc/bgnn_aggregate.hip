@@ -319,6 +319,13 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   }
   float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;   // column sums of the rows this lane wrote, per domain
   float n_s = 0.f, n_t = 0.f;
+  f2 aS01 = {0.f, 0.f}, aS23 = aS01, aT01 = aS01, aT23 = aS01;  // heads == 1: this lane's columns of a_t2s / a_s2t
+  if (p.heads == 1 && fvalid) {
+    aS01.x = p.a_t2s[f0]; aS01.y = f0 + 1 < p.D ? p.a_t2s[f0 + 1] : 0.f;
+    aS23.x = f0 + 2 < p.D ? p.a_t2s[f0 + 2] : 0.f; aS23.y = f0 + 3 < p.D ? p.a_t2s[f0 + 3] : 0.f;
+    aT01.x = p.a_s2t[f0]; aT01.y = f0 + 1 < p.D ? p.a_s2t[f0 + 1] : 0.f;
+    aT23.x = f0 + 2 < p.D ? p.a_s2t[f0 + 2] : 0.f; aT23.y = f0 + 3 < p.D ? p.a_s2t[f0 + 3] : 0.f;
+  }
   // The queue hands out CHUNKS of TQ_CHUNK consecutive tiles: device-scope atomics on ONE address retire at only
   // ~11 M/s (90 ns each, measured), so one atomic per 8-row tile put a floor of 125k tiles x 90 ns / 8 queues = 1.4 ms
   // under the C4 launch -- the kernel took 1.45 ms for 1 to 42 in-edges per row alike.
@@ -380,7 +387,9 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
     const char* __restrict__ Hb = reinterpret_cast<const char*>(H + (int64_t)head * p.ldh + f0c);
 
     f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    if (fvalid) {
+    if (p.heads == 1) {                    // both attention vectors live in registers (loaded once per kernel)
+      a01 = dom_s ? aS01 : aT01; a23 = dom_s ? aS23 : aT23;
+    } else if (fvalid) {
       a01.x = av[f0];
       a01.y = f0 + 1 < p.D ? av[f0 + 1] : 0.f;
       a23.x = f0 + 2 < p.D ? av[f0 + 2] : 0.f;

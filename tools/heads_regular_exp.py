@@ -1,5 +1,6 @@
 import sys, torch, numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bridged_gnn_amd import ops, synth
 dev = "cuda:0"
 n = 1_000_000
@@ -18,7 +19,10 @@ for deg in (1, 4, 11, 21, 42):
     rp = torch.arange(0, n * deg + 1, deg, device=dev, dtype=torch.int32)
     c = ops.DstCSR(rp, src.to(torch.int32).contiguous(), None, n * deg, n)
     t = timeit(lambda: ops.adaptedconv_aggregate(t2s, s2t, a1, a2, c, m8, 2, 0.1, heads=3))
-    print(f"heads=3 regular deg {deg}: {t:.3f} ms ({n*deg/t/1e6:.1f} G edges/s)", flush=True)
+    hS = torch.randn(n, 128, device=dev); hT = torch.randn(n, 128, device=dev); b1 = torch.randn(128, device=dev) * 0.1
+    tw = timeit(lambda: ops.adaptedconv_aggregate(hS, hT, b1, b1, c, m8, 128, 0.1))
+    del hS, hT
+    print(f"heads=3 regular deg {deg}: {t:.3f} ms ({n*deg/t/1e6:.1f} G edges/s) | wide D=128: {tw:.3f} ms ({n*deg/tw/1e6:.1f} G edges/s)", flush=True)
 
 # C4-style graphs: how much of the gap to the regular graph is the far edges, how much the degree mix?
 ns = n // 2
