@@ -235,7 +235,7 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
             if rank == 0:
                 out["graph_replay_ms_per_step"] = f"stalled (> {args.graph_timeout:.0f} s), eager result kept"
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)          # a stalled replay / collective is a failed run: the eager line is printed, the exit code says so
     threading.Thread(target=watchdog, daemon=True).start()
     note = None
     try:
@@ -268,7 +268,7 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
             out["graph_replay_ms_per_step"] = note
             print(json.dumps(out), flush=True)
         if use_dist:
-            os._exit(0)
+            os._exit(4)          # peers may hang in a replayed collective: non-zero after the eager line
         return False
     if out is None:
         return True

@@ -16,6 +16,7 @@ _P, _I64, _I32, _F32, _SZ, _INT = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C
 # name -> (restype, argtypes); mirrors include/bgnn.h one to one
 SIGNATURES = {
     "bgnn_version": (_INT, []),
+    "bgnn_source_hash": (C.c_char_p, []),
     "bgnn_error_string": (C.c_char_p, [_INT]),
     "bgnn_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "bgnn_build_dst_csr": (_INT, [_P, _I64, _I64, _INT, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -53,22 +54,65 @@ SIGNATURES = {
 }
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the library's sources in the Makefile's order -- the same digest the
+    Makefile bakes into the library as `bgnn_source_hash()`; a mismatch means the .so is older than the sources."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for name in _HASHED_SOURCES:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# keep in step with HASHED in csrc/Makefile
+_HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
+                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_common.h", os.path.join("..", "..", "include", "bgnn.h"))
+
+
+def _sidecar_hash():
+    try:
+        with open(os.path.join(_HERE, "csrc", "libbgnn_hip.srchash")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _make():
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "-s"], check=False)
+
+
+def _load():
+    l = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype, fn.argtypes = res, args
+    return l
+
+
 def lib():
-    """Load libbgnn_hip.so; raises (loudly) when it has not been built."""
+    """Load libbgnn_hip.so; raises (loudly) when it has not been built or was built from other sources than the
+    ones next to it (a stale .so would otherwise load silently)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
-            # building the HIP library is not a fallback: same kernels, compiled where they were missing
-            import subprocess
-            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "-s"], check=False)
+        have_hipcc = os.path.exists("/opt/rocm/bin/hipcc")
+        if have_hipcc and (not os.path.exists(SO_PATH) or _sidecar_hash() != source_hash()):
+            # building the HIP library is not a fallback: same kernels, compiled where they were missing or stale
+            # (the sidecar file lets the staleness be seen BEFORE the library is mapped into the process)
+            _make()
         if not os.path.exists(SO_PATH):
             raise RuntimeError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C bridged_gnn_amd/csrc`).  bridged_gnn_amd has no CPU fallback.")
-        l = C.CDLL(SO_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype, fn.argtypes = res, args
+        want = source_hash()
+        l = _load()
+        got = l.bgnn_source_hash().decode()
+        if got != want:
+            raise RuntimeError(
+                f"{SO_PATH} was built from other sources (library {got}, tree {want}): rebuild it with "
+                "`make -C bridged_gnn_amd/csrc` (a loaded library cannot be replaced inside this process)")
         _lib = l
     return _lib
 
@@ -79,13 +123,21 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {msg.decode() if msg else rc} (code {rc})")
 
 
-def ptr(t):
-    """Device pointer of a tensor (None -> NULL); refuses host tensors."""
-    if t is None:
-        return None
+def _check_device(t):
     if not t.is_cuda:
         raise RuntimeError("bridged_gnn_amd ops need CUDA(HIP) tensors; there is no CPU path "
                            f"(got a {t.device} tensor)")
+    if t.device.index != torch._C._cuda_getDevice():
+        # launches go to the CURRENT device's stream: a tensor of another GPU would hand the kernel foreign pointers
+        raise RuntimeError(f"tensor lives on {t.device} but the current device is cuda:{torch._C._cuda_getDevice()}; "
+                           "wrap the call in `with torch.cuda.device(t.device):` (one process drives one GPU here)")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL); refuses host tensors and tensors of a device that is not current."""
+    if t is None:
+        return None
+    _check_device(t)
     if not t.is_contiguous():
         raise RuntimeError("bridged_gnn_amd ops need contiguous tensors")
     return C.c_void_p(t.data_ptr())
@@ -95,9 +147,7 @@ def ptr_rows(t):
     """Device pointer of a 2-D row-strided view (unit column stride, e.g. a column slice of an interleaved table)."""
     if t is None:
         return None
-    if not t.is_cuda:
-        raise RuntimeError("bridged_gnn_amd ops need CUDA(HIP) tensors; there is no CPU path "
-                           f"(got a {t.device} tensor)")
+    _check_device(t)
     if t.dim() != 2 or t.stride(1) != 1:
         raise RuntimeError("expected a 2-D tensor with unit column stride")
     return C.c_void_p(t.data_ptr())

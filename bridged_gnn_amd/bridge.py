@@ -6,7 +6,7 @@ pushes [Ns*B, 128] gathers through the scorer.  Here the per-nod
 scorer is evaluated once per node and the per-pair part is a streaming top-k kernel:
   cosine (`Similar`, `Similar_v2(mode='cosine')`, `Similar_noTrans`; models/models.py:124-130,
           :945-948, :185-189):  q = u + biasatt(u), u = lin_self(z)  per node, then
-          normalise rows and run `bgnn_cosine_topk_f32` (fp32 MFMA);
+          normalise rows and run `bgnn_cosine_topk_f32` (bf16-piece MFMA shortlist pass + canonical fp64 re-score);
   mlp    (`Similar_v2(mode='mlp')`, :949-951): eval-mode BN/Linear are affine, so
           W1.bn1([z_s||z_t]) = A[s] + B[t]; `bgnn_mlp_pair_topk_f32` evaluates
           w2.relu(bn2(A[s]+B[t])) + b2 per pair.

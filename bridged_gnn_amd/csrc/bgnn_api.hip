@@ -2,6 +2,11 @@
 
 extern "C" int bgnn_version(void) { return BGNN_VERSION; }
 
+#ifndef BGNN_SRC_HASH
+#define BGNN_SRC_HASH "unknown"
+#endif
+extern "C" const char* bgnn_source_hash(void) { return BGNN_SRC_HASH; }
+
 extern "C" const char* bgnn_error_string(int code) {
   switch (code) {
     case 0: return "success";

@@ -264,13 +264,8 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-#if !defined(GEMM_EXP) || GEMM_EXP != 1
     if (kt + 1 < nk) sstore(cur ^ 1);            // tile kt+1 (in registers since the previous compute phase)
     if (kt + 2 < nk) gload((kt + 2) * BK);       // tile kt+2 flies during this compute phase
-#endif
-#if defined(GEMM_EXP) && GEMM_EXP == 3
-    if (p.N < 0)
-#endif
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       float4 af[TM], bf[TN];
@@ -345,11 +340,7 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
         float4 o;
         o.x = fmaf(cf, wv.x, v.x + bv.x); o.y = fmaf(cf, wv.y, v.y + bv.y);
         o.z = fmaf(cf, wv.z, v.z + bv.z); o.w = fmaf(cf, wv.w, v.w + bv.w);
-#if defined(GEMM_EXP) && GEMM_EXP == 2
-        if (o.x == 12345.678f) *reinterpret_cast<float4*>(out + row * p.row_stride + cc) = o;   // timing experiment: no stores
-#else
         *reinterpret_cast<float4*>(out + row * p.row_stride + cc) = o;
-#endif
       }
     }
   }
@@ -368,14 +359,6 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
 // tanh through v_exp_f32 + v_rcp_f32 (abs. error < 5e-7; the coefficient scales an O(1) rank-1 term)
 __device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f); }
 
-#if defined(GEMM_EXP) && GEMM_EXP == 20           // tools/gemm_exp.py 20: cycle stamps per phase of the tile loop
-__device__ unsigned long long g_wreg_cnt[8];
-#define WSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define WACC(i, a, b) wdbg[i] += (b) - (a)
-#else
-#define WSTAMP(var)
-#define WACC(i, a, b) do { } while (0)
-#endif
 
 template <int DK, int NCT, int NW, bool BF3, int MODE>
 __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
@@ -602,32 +585,21 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   sstore(0);
   gload(min(tile + (int64_t)gridDim.x, last));
   __builtin_amdgcn_s_waitcnt(0x0F70);         // enter the loop with no load pending (see the comment before the epilogue)
-#if defined(GEMM_EXP) && GEMM_EXP == 20
-  unsigned long long wdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   int it = 0;
   for (; tile < ntiles; ++it, tile += gridDim.x) {   // block-uniform trip count
     const int cur = it & 1;
-    WSTAMP(w0);
     __syncthreads();                          // buffer `cur` is complete; nobody still reads buffer cur^1
-    WSTAMP(w1);
     // tile it+1 goes registers -> LDS, tile it+2 starts flying; past the end the last tile is staged again (never read)
     // (staggering the staging of the two waves that share a SIMD, or two 4-wave blocks per CU, measured no gain)
-#if !defined(GEMM_EXP) || (GEMM_EXP != 13 && GEMM_EXP != 14)
     sstore(cur ^ 1);                                          // tile it+1: registers -> LDS
     gload(min(tile + 2 * (int64_t)gridDim.x, last));          // tile it+2 flies during the MFMA phase
-#endif
     __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMA chain (the scheduler sinks them to their use)
-    WSTAMP(w2);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     {
     if constexpr (!BF3) {
     const float* xb = &xs[cur][(rs * 32 + fr) * LD + 4 * fh];
-#if defined(GEMM_EXP) && GEMM_EXP == 11
-    if (p.N < 0)
-#endif
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const float4 b = *reinterpret_cast<const float4*>(xb + 8 * kb);
@@ -657,12 +629,7 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
     }
     // The loads issued above landed during the MFMA phase; retiring them HERE (vmcnt(0), free) lets the next
     // iteration's staging start without waiting for the stores below (vmcnt counts loads and stores in order).
-#if defined(GEMM_EXP) && GEMM_EXP == 20
-    asm volatile("s_nop 0" ::"v"(acc[15]));
-#endif
-    WSTAMP(w3);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    WSTAMP(w4);
     {
     // epilogue: bias + rank-1 shift in the accumulator layout (lane = row, 4 consecutive columns per q) ...
     const float* pr = pre[cur][rs * 32 + fr];
@@ -715,9 +682,6 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(&cw[((lane >> 3) + 8 * i) * CT_LD + (lane & 7) * 4]);
         const int64_t row = row0 + 8 * i;
-#if defined(GEMM_EXP) && (GEMM_EXP == 12 || GEMM_EXP == 14)
-        if (v.x == 12345.678f)
-#endif
         if (row < p.N) {
           if constexpr (MODE != 2) *reinterpret_cast<float4*>(ocol + row * p.row_stride) = v;
           if constexpr (MODE >= 1) {
@@ -730,8 +694,6 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       }
     }
     }
-    WSTAMP(w5);
-    WACC(0, w0, w1); WACC(1, w1, w2); WACC(2, w2, w3); WACC(3, w3, w4); WACC(4, w4, w5); WACC(5, 0, 1);
     if constexpr (MODE == 2) {
       // the tile's rows leave through red2 in the same iteration (a second barrier per tile; deferring the flush to the
       // next iteration's top put a branch with stores in front of the staging and the compiler drained vmcnt there: 2x slower)
@@ -739,9 +701,6 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       flush2(tile);
     }
   }
-#if defined(GEMM_EXP) && GEMM_EXP == 20
-  if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_wreg_cnt[i], wdbg[i]);
-#endif
   if constexpr (MODE >= 1) {
     if (p.colsum != nullptr) {
       // lanes -> block (ds_add_f32) -> one hardware fp64 atomic per (block, column, domain)
@@ -1191,10 +1150,3 @@ extern "C" int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, con
   return 0;
 }
 
-#if defined(GEMM_EXP) && GEMM_EXP == 20
-extern "C" int bgnn_debug_wreg_counters(unsigned long long* out8) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wreg_cnt), sizeof(z)) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_wreg_cnt), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif

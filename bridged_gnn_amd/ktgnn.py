@@ -266,7 +266,7 @@ class AdaptedConv(nn.Module):
         self.a_g_t2s = Linear(in_channels[0] * 2, 1, bias=False)
         self.a_f_s2t = Linear(out_channels, 1, bias=False)
         self.a_f_t2s = Linear(out_channels, 1, bias=False)
-        self._csr_cache = {}
+        self._csr_cache = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -327,13 +327,15 @@ class AdaptedConv(nn.Module):
         return out[:, :D]
 
     def _csr_for(self, edge_index, num_nodes):
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index.device.index, num_nodes)
-        csr = self._csr_cache.get(key)
-        if csr is None:
+        """CSR of the reference-parity call `conv(x, edge_index, e1, e2, mask)`, cached against the tensor OBJECT and its
+        in-place version (like `_as_u8`): a data_ptr key would hand a stale CSR to a different edge_index that the
+        caching allocator placed on the freed block of the previous one, or to one edited in place."""
+        c = self._csr_cache
+        if c is None or c[0]() is not edge_index or c[1] != edge_index._version or c[2] != num_nodes:
             # edge_index is ALREADY rewritten by graph_partition -> no self-loop rewrite here
             csr = ops.build_dst_csr(edge_index, num_nodes, rewrite_self_loops=False)
-            self._csr_cache = {key: csr}
-        return csr
+            self._csr_cache = c = (weakref.ref(edge_index), edge_index._version, num_nodes, csr)
+        return c[3]
 
     def forward(self, x, edge_index, edge_index1=None, edge_index2=None, central_mask=None, size=None,
                 csr=None, delta=None, epilogue=None, return_alpha=False, colsum=None, sums=None):
@@ -563,7 +565,10 @@ class KTGNN_no_complement(nn.Module):
         if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:
             logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr)                      # :432
             logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr)                  # :434
-            xt = self.clf_transformer(x) if self.training else self._transformer_eval(x)
+            # the folded / raw-kernel eval form has no autograd: with grad enabled (fine-tuning with frozen BN, input
+            # attribution) the module itself runs -- eval-mode BatchNorm is autograd-safe
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.clf_transformer.parameters()))
+            xt = self.clf_transformer(x) if (self.training or needs_grad) else self._transformer_eval(x)
             logits_hat = self.clf_target(xt.contiguous(), None, central_mask=central_mask, csr=csr)       # :433
         else:
             # the three classifier convs share the graph: their six narrow tables are interleaved per node

@@ -32,6 +32,9 @@ extern "C" {
 
 int bgnn_version(void);
 const char* bgnn_error_string(int code);
+/* digest of the sources this library was built from (csrc/Makefile: HASHED); the loader compares it with the
+ * tree next to the library so that a stale build cannot load silently.                         */
+const char* bgnn_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------
  * (a10) graph_partition -> by-destination CSR.         models/KTGNN.py:385-398, cached :409-412
