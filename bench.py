@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on MI355X: aggregated edges/s of the KT-GNN eval forward
-(4 AdaptedConv calls: hidden conv + 3 classifier convs, reference models/KTGNN.py:401-435) on the
-synthetic 1M-node / 20M-edge bridged graph (config C4, hidden_dim=128), plus kNN-bridge pairs/s
-(config C5) as an extra field.  One JSON line on rank 0.
+(4 AdaptedConv calls: hidden conv + 3 classifier convs, reference models/KTGNN.py:401-435) plus
+kNN-bridge pairs/s (config C5) as an extra field.  One JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 20 --warmup 5                 # config C4: 1M nodes / 20M edges, hidden 128
+  python bench.py --config c3                                    # config C3: Twitter_Graph stand-in, F=300, hidden 128
+  python bench.py --config c2                                    # config C2: Sync-RD_intra 10k nodes, hidden 64
+  python bench.py --config c5                                    # config C5 alone: 100k x 100k cosine kNN bridge
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,6 +16,7 @@ all_to_all of the classifier stage's halo rows per forward over RCCL; the halo r
 features (static data, like the graph) live next to a rank's own rows and are transformed locally.
 After the eager measurement the same K steps are timed as replays of a HIP graph of the forward
 (outputs checked against the eager ones); the faster execution is `value`, both are in the line.
+`parity` = the timed forward's own outputs against the CPU oracle (all rows at N=1, part of the cpu_baseline leg).
 """
 import argparse
 import json
@@ -28,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+L2_GATHER_GBS = 17800.0        # same guide, "Indexed rows": 16.8-18.8 TB/s chip-wide for row gathers served from the XCD L2s
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the guide's ~2.5 PF)
+PMC_DIR = os.path.join("profiles", "r02")
 
 
 def agg_bytes(E, N, D):
@@ -35,18 +41,19 @@ def agg_bytes(E, N, D):
     return E * (4 * D + 4) + N * (8 * D + 4) + 4
 
 
-def pmc_traffic(args, world):
+def pmc_traffic(args, world, graph):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    are collected in separate profiler runs -- profiles/r01/README.md -- they cannot be read live here).  Only
-    reported when this run's workload is the one those passes measured."""
+    need separate profiler runs -- profiles/r02/README.md -- they cannot be read live here).  Only reported when this
+    run's workload is the one those passes measured; the file is named in the line (`traffic_source`)."""
+    rel = os.path.join(PMC_DIR, f"pmc_traffic_{args.config}_{graph}.json")
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, rel)))
         w = t["workload"]
-        if world == 1 and (w["nodes"], w["edges"], w["hidden"], w["graph"]) == (args.nodes, args.edges, args.hidden, args.graph):
-            return float(t["hbm_bytes_per_launch"])
+        if world == 1 and (w["nodes"], w["edges"], w["hidden"], w["graph"]) == (args.nodes, args.edges, args.hidden, graph):
+            return float(t["hbm_bytes_per_launch"]), rel
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def parse():
@@ -54,13 +61,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c4",
+                    help="BASELINE.json config: c4 (default) is the one the metric is quoted on; c5 = kNN bridge alone")
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=20_000_000)
-    ap.add_argument("--hidden", type=int, default=128)
-    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--feat", type=int, default=None)
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--graph", choices=["local", "uniform"], default="local",
-                    help="local: bridged/kNN-like locality (p_local=0.9, clusters of 1024); uniform: adversarial")
+                    help="c4: local = bridged/kNN-like locality (p_local=0.9, clusters of 1024); uniform = adversarial")
+    ap.add_argument("--no-uniform", action="store_true", help="c4: skip the uniform-random graph's hidden aggregation (the conservative roofline figure)")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--knn-n", type=int, default=100_000)
@@ -71,26 +81,51 @@ def parse():
                          "of the (static) input features resident and transforming them locally")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 code path with several ranks sharing one GPU (payload staged through the host)")
-    ap.add_argument("--graph-replay", action="store_true", help="(default behaviour now; kept for old command lines)")
+    ap.add_argument("--graph-replay", action="store_true", help="(default behaviour; kept for old command lines)")
     ap.add_argument("--no-graph-replay", action="store_true",
                     help="skip the HIP-graph phase: by default the forward (collectives included) is captured once after the "
                          "eager measurement, checked against the eager outputs and timed for the same K steps; the faster "
                          "of the two is `value`, both are reported")
     ap.add_argument("--graph-timeout", type=float, default=60.0,
-                    help="seconds the HIP-graph phase may take before the eager result is printed and the process exits")
-    return ap.parse_args()
+                    help="seconds the HIP-graph phase may take before the eager result is printed and the process exits non-zero")
+    args = ap.parse_args()
+    dflt = {"c2": (64, 64), "c3": (300, 128), "c4": (128, 128), "c5": (128, 128)}[args.config]
+    args.feat = dflt[0] if args.feat is None else args.feat
+    args.hidden = dflt[1] if args.hidden is None else args.hidden
+    return args
 
 
-def make_graph(args):
+# ------------------------------------------------------------------------------------------------ workloads
+def c4_graph(nodes, edges, graph="local"):
+    """C4: per node 6 within-domain in-neighbours, per target node 20 source in-neighbours, the rest random
+    intra-domain edges; `local` draws a neighbour from the node's own cluster of 1024 consecutive ids w.p. 0.9."""
     from bridged_gnn_amd import synth
-    n_src = args.nodes // 2
-    n_tar = args.nodes - n_src
-    per_node = 6
-    k_cross = 20
-    extra = args.edges - per_node * args.nodes - k_cross * n_tar
-    ei, mask = synth.bridged_graph(n_src, n_tar, k_within=per_node, k_cross=k_cross, n_extra=max(extra, 0),
-                                   cluster=1024, p_local=0.9 if args.graph == "local" else 0.0, seed=0)
-    return ei, mask
+    n_src = nodes // 2
+    n_tar = nodes - n_src
+    extra = edges - 6 * nodes - 20 * n_tar
+    return synth.bridged_graph(n_src, n_tar, k_within=6, k_cross=20, n_extra=max(extra, 0), cluster=1024,
+                               p_local=0.9 if graph == "local" else 0.0, seed=0)
+
+
+def make_workload(args, dev):
+    """-> dict(name, ei_np (int64 [2,E] = the model's edge_index), mask_np, x (device tensor))"""
+    from bridged_gnn_amd import synth, utils
+    gen = torch.Generator(device=dev).manual_seed(0)
+    if args.config == "c4":
+        ei_np, mask_np = c4_graph(args.nodes, args.edges, args.graph)
+        return {"name": f"C4 synthetic bridged graph ({args.graph})", "ei_np": ei_np, "mask_np": mask_np,
+                "x": torch.randn(mask_np.shape[0], args.feat, device=dev, generator=gen)}
+    if args.config == "c3":
+        x, ei, y, m = synth.twitter_standin(seed=0)
+        und = utils.to_undirected(torch.from_numpy(ei).to(dev), x.shape[0])       # run.sh:7 --to_undirected
+        return {"name": "C3 Twitter_Graph stand-in (581 S + 20230 T, kNN + 0.9M random edges, undirected)",
+                "ei_np": und.cpu().numpy(), "mask_np": m, "x": torch.from_numpy(x).to(dev)}
+    if args.config == "c2":
+        x, ei, y, m = synth.sync_rd_intra(n=10000, feat=args.feat, homophily=0.7, deg=10, k_cross=20, seed=0)
+        und = utils.to_undirected(torch.from_numpy(ei).to(dev), x.shape[0])
+        return {"name": "C2 Sync-RD_intra 10k nodes / 70% homophily (undirected)", "ei_np": und.cpu().numpy(), "mask_np": m,
+                "x": torch.from_numpy(x).to(dev)}
+    raise ValueError(args.config)
 
 
 def build_model(args, dev):
@@ -106,53 +141,6 @@ def build_model(args, dev):
     return model.to(dev).eval()
 
 
-def cpu_baseline(args):
-    """The oracle's C port (oracle/oracle_c.c, OpenMP) timed on the host cores on a bounded sample:
-    one eval forward of the same model on the same generator at 1/4 scale (about 10 s of host work)."""
-    from bridged_gnn_amd import synth
-    from oracle import oracle_c as OC
-    from oracle import oracle_np as O
-    n = max(args.nodes // 4, 1000)
-    ns = n // 2
-    extra = max(args.edges // 4 - 6 * n - 20 * (n - ns), 0)
-    ei, mask = synth.bridged_graph(ns, n - ns, 6, 20, extra, cluster=1024,
-                                   p_local=0.9 if args.graph == "local" else 0.0, seed=0)
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((n, args.feat)).astype(np.float32)
-    model = build_model(args, "cpu")
-    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
-    rowptr, col, _ = O.dst_csr(ei, mask)
-    E = int(rowptr[-1])
-
-    def conv(xx, prefix):
-        p = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-        hs2t, ht2s = OC.adaptedconv_transform(xx, mask, p)
-        return OC.adaptedconv_aggregate(ht2s, hs2t, p["a_f_t2s.weight"], p["a_f_s2t.weight"], rowptr, col, mask)
-
-    def fwd():
-        h = conv(x, "convs.0.")
-        bn = {k[len("bns.0."):]: v for k, v in sd.items() if k.startswith("bns.0.")}
-        h = np.maximum((h - bn["running_mean"]) / np.sqrt(bn["running_var"] + 1e-5) * bn["weight"] + bn["bias"], 0).astype(np.float32)
-        a = conv(h, "clf_base.")
-        t = h @ sd["clf_transformer.0.weight"].T + sd["clf_transformer.0.bias"]
-        b1 = {k[len("clf_transformer.1."):]: v for k, v in sd.items() if k.startswith("clf_transformer.1.")}
-        t = np.maximum((t - b1["running_mean"]) / np.sqrt(b1["running_var"] + 1e-5) * b1["weight"] + b1["bias"], 0).astype(np.float32)
-        t = (t @ sd["clf_transformer.3.weight"].T + sd["clf_transformer.3.bias"]).astype(np.float32)
-        b = conv(t, "clf_target.")
-        c = conv(h, "clf_target.")
-        return O.log_softmax(a), O.log_softmax(c), O.log_softmax(b)
-
-    fwd()
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        fwd()
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    return {"value": 4 * E / t, "unit": "edges/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
-            "sample": f"same generator at N={n} nodes / E'={E} edges (1/4 scale), 1 eval forward, median of 3: {t:.3f} s"}
-
-
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -163,9 +151,110 @@ def cpu_model():
     return "unknown"
 
 
-def knn_cpu_baseline(n, k=20, sample_queries=8192):
-    """The oracle's C port of the cosine kNN (OpenMP, exhaustive canonical scores + top-k) on a bounded sample of C5:
-    `sample_queries` query rows against all n candidates."""
+# ------------------------------------------------------------------------------------------------ CPU legs (oracle)
+def parity_report(ref, gpu_out, rows):
+    """the timed forward's outputs against the oracle's: rtol 1e-5 + atol 1e-6 max|ref| (tests/conftest.py:assert_close)"""
+    parity = {"rows_checked": int(rows), "checker": "oracle/oracle_c.c full forward on the same inputs",
+              "bar": "rtol 1e-5 + atol 1e-6 * max|ref| per output"}
+    worst, ok = 0.0, True
+    for name, r, g in zip(("base", "target", "target_hat"), ref, gpu_out):
+        g = g.cpu().numpy()
+        err = np.abs(g.astype(np.float64) - r)
+        tol = 1e-5 * np.abs(r) + 1e-6 * np.abs(r).max()
+        parity[f"max_abs_err_{name}"] = float(err.max())
+        worst = max(worst, float((err / tol).max()))
+        ok = ok and bool((err <= tol).all())
+    parity["max_err_over_tolerance"] = worst          # <= 1 : every element inside the bar
+    parity["within_1e-5"] = ok
+    return parity
+
+
+def cpu_baseline(args, model, wl, gpu_out):
+    """The oracle's C port (oracle/oracle_c.c, OpenMP) of the SAME eval forward on the SAME inputs, timed on the host
+    cores.  Its first (warm-up) run doubles as the checker of the timed GPU forward's outputs (`parity`): every row of
+    the three log-prob outputs.  When one forward takes the host longer than ~12 s (few cores) the timing falls back to
+    a quarter-scale graph of the same generator and the full-size check is skipped."""
+    from oracle import oracle_c as OC
+    from oracle import oracle_np as O
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ei, mask = wl["ei_np"], wl["mask_np"]
+    quarter = None
+    if args.config == "c4":                                  # probe the host's speed on the quarter-scale graph first
+        n4 = max(args.nodes // 4, 1000)
+        ei4, mask4 = c4_graph(n4, args.edges // 4, args.graph)
+        x4 = np.random.default_rng(0).standard_normal((n4, args.feat)).astype(np.float32)
+        rp4, col4, _ = O.dst_csr(ei4, mask4)
+        OC.ktgnn_forward_eval(x4, rp4, col4, mask4, sd)
+        t0 = time.perf_counter()
+        OC.ktgnn_forward_eval(x4, rp4, col4, mask4, sd)
+        quarter = (time.perf_counter() - t0, int(rp4[-1]), n4, (x4, rp4, col4, mask4))
+    full = quarter is None or quarter[0] * 4 < 12.0
+    parity = None
+    if full:
+        x = wl["x"].cpu().numpy()
+        rowptr, col, _ = O.dst_csr(ei, mask)
+        E = int(rowptr[-1])
+        ref = OC.ktgnn_forward_eval(x, rowptr, col, mask, sd)          # warm-up run = the checker
+        parity = parity_report(ref, gpu_out, mask.shape[0])
+        run = lambda: OC.ktgnn_forward_eval(x, rowptr, col, mask, sd)
+        sample = f"the same graph and inputs at full size (N={mask.shape[0]}, E'={E})"
+    else:
+        x4, rp4, col4, mask4 = quarter[3]
+        E = quarter[1]
+        run = lambda: OC.ktgnn_forward_eval(x4, rp4, col4, mask4, sd)
+        sample = f"same generator at N={quarter[2]} nodes / E'={E} edges (1/4 scale; the host is too slow for full size)"
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    base = {"value": 4 * E / t, "unit": "edges/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
+            "what": "fused C/OpenMP port of the eval forward (oracle/oracle_c.c)",
+            "sample": f"{sample}, 1 eval forward, median of 3: {t:.3f} s"}
+    return base, parity
+
+
+def cpu_baseline_torch(args, model):
+    """SURVEY 8(d)'s CPU baseline: the op sequence the reference's PyG path executes (index_select / elementwise /
+    index_add_ scatter, dense Linear), restated in plain CPU torch (oracle/oracle_torch.py, forward pinned to the
+    reference's golden vectors), median of 5 runs (3 when a run takes the host > 6 s) on a 1/16-scale graph of the same
+    generator.  Threads: at most 32 -- torch's CPU index_add_ gets SLOWER beyond that (33 s per forward on 256 threads)."""
+    from oracle import oracle_torch as OT
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    n = max(args.nodes // 16, 1000)
+    ei, mask = c4_graph(n, args.edges // 16, args.graph)
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((n, args.feat)).astype(np.float32))
+    mo = torch.from_numpy(mask)
+    e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
+    E = int(e1.shape[1] + e2.shape[1])
+    ref = type(model)(args.feat, args.classes, 2, args.hidden, root_weight=False, use_bn=True, dim_share=args.feat)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    ref.eval()
+    conv = lambda c, xx: OT.adaptedconv(xx, mo, e1, e2, dict(c.named_parameters()))
+
+    def fwd():
+        with torch.no_grad():
+            h = torch.relu(ref.bns[0](conv(ref.convs[0], x)))
+            return (torch.log_softmax(conv(ref.clf_base, h), 1), torch.log_softmax(conv(ref.clf_target, h), 1),
+                    torch.log_softmax(conv(ref.clf_target, ref.clf_transformer(h)), 1))
+    t0 = time.perf_counter()
+    fwd()
+    runs = 5 if time.perf_counter() - t0 < 6.0 else 3
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fwd()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {"value": 4 * E / t, "unit": "edges/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "what": "reference-shaped torch op sequence (index_select / index_add_), oracle/oracle_torch.py",
+            "sample": f"same generator at N={n} / E'={E} (1/16 scale), 1 eval forward, median of {runs}: {t:.3f} s"}
+
+
+def knn_cpu_baselines(n, k=20, sample_queries=8192):
+    """(i) the oracle's C port of the cosine kNN (OpenMP, exhaustive canonical fp64 scores + top-k) and (ii) the GEMM
+    restatement SURVEY 8(d) asks for (torch sgemm + topk on the host), each on `sample_queries` of the query rows."""
     from bridged_gnn_amd import synth
     from oracle import oracle_c as OC
     nq = min(sample_queries, n)
@@ -175,8 +264,20 @@ def knn_cpu_baseline(n, k=20, sample_queries=8192):
     t0 = time.perf_counter()
     OC.cosine_topk(q, c, k)
     t = time.perf_counter() - t0
-    return {"value": float(nq) * n / t, "unit": "pairs/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
+    port = {"value": float(nq) * n / t, "unit": "pairs/s", "cores": OC.num_threads(), "cpu": cpu_model(), "kind": "port",
+            "what": "exhaustive canonical fp64 scores + top-k (oracle/oracle_c.c)",
             "sample": f"{nq} of the {n} query rows against all {n} candidates, d=128 k={k}: {t:.2f} s"}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    qt, ct = torch.from_numpy(q), torch.from_numpy(c).t().contiguous()
+    (qt[:256] @ ct).topk(k, dim=1)
+    t0 = time.perf_counter()
+    for s in range(0, nq, 1024):
+        torch.sigmoid(qt[s:s + 1024] @ ct).topk(k, dim=1, largest=True, sorted=False)      # main_bridged_graph.py:59-60
+    t = time.perf_counter() - t0
+    gemm = {"value": float(nq) * n / t, "unit": "pairs/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "what": "GEMM restatement: per-node normalised q, torch sgemm + sigmoid + topk in batches of 1024 queries",
+            "sample": f"{nq} of the {n} query rows against all {n} candidates: {t:.2f} s"}
+    return port, gemm
 
 
 def max_over_ranks(vals, dev):
@@ -188,45 +289,56 @@ def max_over_ranks(vals, dev):
     return [float(v) for v in t.tolist()]
 
 
+# ------------------------------------------------------------------------------------------------ C5: kNN bridge
 def knn_bench(args, dev, rank=0, world=1):
-    """C5: cosine kNN bridge.  N>1: query rows are sharded over the ranks (candidates replicated, no collective in
-    the data path -- SURVEY 8(e)); the job time is the max over ranks."""
-    from bridged_gnn_amd import ops, synth
+    """C5: cosine kNN bridge through the library's sharded entry point (bridge.sharded_cosine_topk_edges): query rows
+    are sharded over the ranks, each rank normalises ITS slice of the candidates and one all_gather makes them whole
+    (SURVEY 8(e)); the job time is the max over ranks.  The top-k call itself is timed with HIP events on the launch stream."""
+    from bridged_gnn_amd import bridge, synth
     n = args.knn_n
-    q_all = synth.gaussian_embeddings(n, 128, seed=0)
     lo, hi = rank * n // world, (rank + 1) * n // world
-    q = torch.from_numpy(q_all[lo:hi]).to(dev)
-    c = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=1)).to(dev)
-    ts = []
+    q = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=0)[lo:hi]).to(dev)
+    c_mine = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=1)[lo:hi]).to(dev)   # this rank's share of the candidates
+    ts, ks = [], []
     for it in range(4):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        qn, cn = ops.l2_normalize_rows(q), ops.l2_normalize_rows(c)
-        idx, val, nfb = ops.cosine_topk(qn, cn, 20)
-        ei = ops.coalesce(ops.topk_edges(idx, cand_base=0, query_base=lo))
+        ei, idx, val, nfb = bridge.sharded_cosine_topk_edges(q, c_mine, 20, rank=rank, world=world, query_base=lo, events=(s, e))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
             dt = max_over_ranks([dt], dev)[0]
         ts.append(dt)
+        ks.append(s.elapsed_time(e))
     t = float(np.median(ts[1:]))
+    tk = float(np.median(ks[1:])) * 1e-3
     pairs = float(n) * float(n)
+    pairs_rank = float(hi - lo) * float(n)
+    pieces = 3                                   # hi.hi + hi.mid + mid.hi bf16 MFMA products per fp32 product (DESIGN 4.4)
+    issued = pairs_rank * 256 * pieces / tk / 1e12
     return {"workload": f"C5 cosine kNN {n}x{n} d=128 k=20 (normalise + score + top-k + coalesce)"
-                        + (f", query rows sharded x{world}" if world > 1 else ""),
+                        + (f", query rows sharded x{world}, one all_gather of the candidates" if world > 1 else ""),
             "pairs_per_s": pairs / t, "ms": t * 1e3, "fallback_rows": int(nfb.item()), "edges_this_rank": int(ei.shape[1]),
-            # algorithmic flops (2 d per pair) against the fp32 MFMA/VALU peak; pass 1 computes them as bf16 piece products
-            # on the bf16 matrix cores, which is how the ratio can approach / exceed 1
-            "mfma_fp32_frac": (pairs * 256 / t) / (157.3e12 * world)}
+            "roofline": {"bound": "mfma", "kernel": "bgnn_cosine_topk_f32 (pass 1 shortlist on bf16 MFMA + fp64 refine + fallback)",
+                         "achieved": issued, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "ms_per_launch": tk * 1e3, "bf16_products_per_pair_term": pieces,
+                         "algorithmic_tflops": pairs_rank * 256 / tk / 1e12,
+                         "note": "achieved = bf16 MFMA flops actually issued (2 d x 3 piece products per pair); "
+                                 "algorithmic_tflops = 2 d per pair"}}
 
 
-def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
+# ------------------------------------------------------------------------------------------------ HIP-graph phase
+def graph_phase(args, runner, barrier, use_dist, dev, rank, world, out, units):
     """Capture ONE forward (every launch of it, and at N>1 its RCCL collectives) into a HIP graph, check the replayed
     outputs against an eager forward on every rank, time the same K steps as replays.  `out` (rank 0's result line,
     already complete from the eager measurement) is switched to the replay numbers only when every rank verified its
-    outputs and the replay is faster.  A watchdog prints the eager line and ends the process if the phase stalls (a
-    graph-launched collective is the one thing here that cannot be rehearsed on a one-GPU box)."""
+    outputs and the replay is faster.  The ranks agree through the rendezvous STORE (host side, no collective) whether
+    everybody captured before anybody replays, so a failed capture is a clean fallback to the eager line; a replay that
+    stalls (a graph-launched collective is the one thing that cannot be rehearsed on a one-GPU box) trips the watchdog,
+    which prints the eager line and exits NON-ZERO."""
     import threading
     done = threading.Event()
 
@@ -237,7 +349,7 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
                 print(json.dumps(out), flush=True)
             os._exit(3)          # a stalled replay / collective is a failed run: the eager line is printed, the exit code says so
     threading.Thread(target=watchdog, daemon=True).start()
-    note = None
+    note, g, got, ref, gdt = None, None, None, None, None
     try:
         with torch.no_grad():
             ref = [t.clone() for t in runner()[:3]]
@@ -245,36 +357,39 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 got = runner()[:3]
-            for _ in range(3):
-                g.replay()
-            barrier()
-            ok = all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(got, ref))
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                g.replay()
-            barrier()
-            gdt = time.perf_counter() - t0
-        gdt, bad = max_over_ranks([gdt, 0.0 if ok else 1.0], dev) if use_dist else (gdt, 0.0 if ok else 1.0)
-        graph_ms = gdt / args.steps * 1e3
-        if bad:
-            note = "replayed outputs differ from the eager outputs, eager result kept"
     except Exception as exc:                              # the eager measurement stands
         note = f"capture failed: {type(exc).__name__}: {str(exc)[:120]}"
+    if use_dist and world > 1:
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        store.set(f"bgnn_capture_{rank}", "0" if note else "1")
+        flags = [store.get(f"bgnn_capture_{r}").decode() for r in range(world)]      # blocks until every rank has posted
+        if note is None and "0" in flags:
+            note = "capture failed on another rank, eager result kept"
+    if note is None:
+        try:
+            with torch.no_grad():
+                for _ in range(3):
+                    g.replay()
+                barrier()
+                ok = all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(got, ref))
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    g.replay()
+                barrier()
+                gdt = time.perf_counter() - t0
+            gdt, bad = max_over_ranks([gdt, 0.0 if ok else 1.0], dev) if use_dist else (gdt, 0.0 if ok else 1.0)
+            if bad:
+                note = "replayed outputs differ from the eager outputs, eager result kept"
+        except Exception as exc:
+            note = f"replay failed: {type(exc).__name__}: {str(exc)[:120]}"
     done.set()
-    if note is not None and note.startswith("capture failed"):
-        # this rank cannot know whether its peers captured: they may be waiting in a replayed collective (their own
-        # watchdogs end them).  Do not meet them at a barrier -- print the eager line and leave.
-        if out is not None:
-            out["graph_replay_ms_per_step"] = note
-            print(json.dumps(out), flush=True)
-        if use_dist:
-            os._exit(4)          # peers may hang in a replayed collective: non-zero after the eager line
-        return False
     if out is None:
-        return True
+        return
     if note is not None:
         out["graph_replay_ms_per_step"] = note
-        return True
+        return
+    graph_ms = gdt / args.steps * 1e3
     out["graph_replay_ms_per_step"] = graph_ms
     if graph_ms < out["ms_per_step"]:
         out["ms_per_step"] = graph_ms
@@ -282,7 +397,48 @@ def graph_phase(args, runner, barrier, use_dist, dev, rank, out, units):
         out["config"]["execution"] = ("HIP-graph replay: the whole forward (all launches" +
                                       (" and the RCCL collectives" if use_dist else "") +
                                       ") captured once, outputs checked against the eager forward, K replays timed")
-    return True
+
+
+class AggTimer:
+    """HIP events on the launch stream (torch's current stream is the stream handed to the C ABI) around every
+    aggregation launch of width `D` while `.on`."""
+
+    def __init__(self, D):
+        from bridged_gnn_amd import ops
+        self.D, self.on, self.ev = D, False, []
+        self.orig = ops.adaptedconv_aggregate
+        ops.adaptedconv_aggregate = self
+
+    def __call__(self, *a, **k):
+        D = a[6] if len(a) > 6 else k["D"]
+        if D == self.D and self.on:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(*a, **k)
+            e.record()
+            self.ev.append((s, e))
+            return r
+        return self.orig(*a, **k)
+
+    def take_ms(self, steps):
+        ms = float(np.sum([s.elapsed_time(e) for s, e in self.ev])) / steps if self.ev else float("nan")
+        self.ev = []
+        return ms
+
+
+def time_forward(runner, steps, warmup, barrier, timer):
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = runner()
+        barrier()
+        timer.on = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = runner()
+        barrier()
+        dt = time.perf_counter() - t0
+    timer.on = False
+    return dt, out
 
 
 def main():
@@ -307,18 +463,36 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from bridged_gnn_amd import ops
-    from bridged_gnn_amd.data import Data
+    def barrier():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
 
-    ei_np, mask_np = make_graph(args)
+    if args.config == "c5":                              # the kNN bridge alone
+        knn = knn_bench(args, dev, rank, world)
+        if rank == 0:
+            out = {"metric": "knn_bridge_pairs_per_sec", "value": knn["pairs_per_s"], "unit": "pairs/s", "n_gpus": world,
+                   "steps": 3, "warmup": 1, "ms_per_step": knn["ms"], "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "f32 (bf16-piece MFMA shortlist, fp64 canonical re-score)", "data": "synthetic",
+                   "config": {"workload": knn["workload"], "parallelism": "single" if world == 1 else f"query rows x{world}"},
+                   "roofline": knn["roofline"], "fallback_rows": knn["fallback_rows"]}
+            if world == 1 and not args.no_cpu:
+                out["cpu_baseline"], out["cpu_baseline_gemm"] = knn_cpu_baselines(args.knn_n)
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
+
+    from bridged_gnn_amd.data import Data
+    wl = make_workload(args, dev)
+    ei_np, mask_np = wl["ei_np"], wl["mask_np"]
     N = mask_np.shape[0]
     model = build_model(args, dev)
-    gen = torch.Generator(device=dev).manual_seed(0)
-    x_full = None
+    timer = AggTimer(args.hidden)
 
     if not use_dist:
-        x = torch.randn(N, args.feat, device=dev, generator=gen)
-        data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), central_mask=torch.from_numpy(mask_np).to(dev))
+        data = Data(x=wl["x"], edge_index=torch.from_numpy(ei_np).to(dev), central_mask=torch.from_numpy(mask_np).to(dev))
         t0 = time.perf_counter()
         csr = model._prepare(data)
         torch.cuda.synchronize()
@@ -328,71 +502,57 @@ def main():
         par = "single"
     else:
         from bridged_gnn_amd.dist import PartitionedKTGNN
-        x_full = torch.randn(N, args.feat, device=dev, generator=gen)     # same seed on every rank
         t0 = time.perf_counter()
         pk = PartitionedKTGNN(model, ei_np, mask_np, rank, world, dev, always_communicate=args.force_dist,
                               cache_input_halo=not args.no_input_halo_cache)
         torch.cuda.synchronize()
         csr_ms = (time.perf_counter() - t0) * 1e3
         Eprime = pk.global_num_edges
-        x_local = x_full[pk.owned_global].contiguous()
-        del x_full
+        x_local = wl["x"][pk.owned_global].contiguous()          # the same seed on every rank
+        wl["x"] = None
         runner = lambda: pk.forward(x_local)
         par = (f"dst-node-partition x{world}; per forward 2 small all-reduces (domain sums) + 1 all_to_all of the classifier "
                f"stage's 48-byte halo rows; " +
                ("halo rows of the static input features resident (fetched once per version of x), transformed locally"
                 if not args.no_input_halo_cache else "hidden conv's 512-byte halo rows exchanged every forward"))
 
-    # ---- per-launch timing of the dominant kernel (hidden-conv aggregation) with HIP events on the
-    #      launch stream (torch's current stream is the stream handed to the C ABI)
-    ev = []
-    orig = ops.adaptedconv_aggregate
-
-    def timed_agg(*a, **k):
-        D = a[6] if len(a) > 6 else k["D"]
-        if D == args.hidden and timed_agg.on:
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(*a, **k)
-            e.record()
-            ev.append((s, e))
-            return r
-        return orig(*a, **k)
-    timed_agg.on = False
-    ops.adaptedconv_aggregate = timed_agg
-
-    def barrier():
-        if use_dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            runner()
-        barrier()
-        timed_agg.on = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            runner()
-        barrier()
-        dt = time.perf_counter() - t0
-    timed_agg.on = False
+    dt, gpu_out = time_forward(runner, args.steps, args.warmup, barrier, timer)
     if use_dist:
         dt = max_over_ranks([dt], dev)[0]
     ms_step = dt / args.steps * 1e3
     # per STEP: the partitioned path aggregates a conv in two launches (interior rows, then boundary rows)
-    agg_ms = float(np.sum([s.elapsed_time(e) for s, e in ev])) / args.steps if ev else float("nan")
+    agg_ms = timer.take_ms(args.steps)
+    gpu_out = [t.clone() for t in gpu_out[:3]]
+    checksums = [float(t.double().sum().item()) for t in gpu_out]        # of THIS rank's rows
+
+    # ---- the conservative roofline figure: the same hidden aggregation on the uniform-random variant of the graph (no
+    #      neighbour reuse for the L2 to exploit; SURVEY 8(d) "also run the adversarial uniform-random variant")
+    uniform = None
+    if args.config == "c4" and args.graph == "local" and not use_dist and not args.no_uniform:
+        ei_u, mask_u = c4_graph(args.nodes, args.edges, "uniform")
+        model_u = build_model(args, dev)
+        data_u = Data(x=wl["x"], edge_index=torch.from_numpy(ei_u).to(dev), central_mask=torch.from_numpy(mask_u).to(dev))
+        e_u = model_u._prepare(data_u).num_edges
+        k_u = max(args.steps // 2, 5)
+        time_forward(lambda: model_u(data_u), k_u, 3, barrier, timer)
+        ms_u = timer.take_ms(k_u)
+        b_u = agg_bytes(e_u, N, args.hidden)
+        tr_u, src_u = pmc_traffic(args, world, "uniform")
+        uniform = {"ms_per_launch": ms_u, "bytes_per_launch": b_u, "achieved": b_u / (ms_u * 1e-3) / 1e9,
+                   "frac": b_u / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr_u, "traffic_source": src_u,
+                   "hbm_frac": (tr_u / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr_u else None}
+        del model_u, data_u
 
     train = None
     if args.train_steps > 0 and not use_dist:
         # one optimisation step = train-mode forward (dropout, batch-stat BN) + HIP backward + Adam
         import torch.nn.functional as F
+        gen = torch.Generator(device=dev).manual_seed(1)
         model.train()
         y = torch.randint(0, args.classes, (N,), device=dev, generator=gen)
         tm = torch.rand(N, device=dev, generator=gen) < 0.5
         cm = data.central_mask
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-3, fused=True)   # same update, one launch
-
         tmt = tm & ~cm
         w_b, w_t = tm.float() / tm.sum(), tmt.float() / tmt.sum()
         yi = y[:, None]
@@ -417,41 +577,57 @@ def main():
             step()
         torch.cuda.synchronize()
         train = {"ms_per_train_step": (time.perf_counter() - t0) / args.train_steps * 1e3, "steps": args.train_steps,
-                 "what": "train-mode forward + backward (HIP kernels: pull aggregation backward, prep / Gram / W-stationary transform backward) + fused Adam on C4"}
+                 "what": "train-mode forward + backward (HIP kernels: pull aggregation backward, prep / Gram / W-stationary transform backward) + fused Adam"}
         model.eval()
-    knn = knn_bench(args, dev, rank, world) if not args.no_knn else None     # every rank takes part when N > 1
+    knn = knn_bench(args, dev, rank, world) if (not args.no_knn and args.config == "c4") else None   # every rank takes part
     out = None
     if rank == 0:
         n_local = N if not use_dist else len(pk.owned_global)
         e_local = Eprime if not use_dist else pk.local_num_edges
         bytes_launch = agg_bytes(e_local, n_local, args.hidden)
         achieved = bytes_launch / (agg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args, world, args.graph if args.config == "c4" else "fixed")
+        gather_bytes = e_local * 4 * args.hidden                       # the row gathers alone (what the L2s serve)
+        roof = {"bound": "hbm", "kernel": f"agg_wide_kernel<D={args.hidden}> (hidden AdaptedConv aggregation)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms,
+                "note": "achieved/frac follow SURVEY 8(d): ALGORITHMIC bytes / launch time.  On a graph with neighbour "
+                        "locality most gathers are L2 hits, so frac can exceed 1 and is not a bound there; the bounds are "
+                        "`uniform_graph.frac` (no reuse to exploit), `hbm_frac` (PMC bytes at the HBM pins / time / peak) and "
+                        "`l2_gather_frac` (gathered bytes / time against the measured L2 row-gather rate)",
+                "hbm_frac": (traffic / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "l2_gather_frac": gather_bytes / (agg_ms * 1e-3) / 1e9 / L2_GATHER_GBS, "l2_gather_peak": L2_GATHER_GBS}
+        if uniform is not None:
+            roof["uniform_graph"] = uniform
         out = {
             "metric": "aggregated_edges_per_sec_ktgnn_fwd", "value": 4 * Eprime / (ms_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C4 synthetic bridged graph N={N} E'={Eprime} ({args.graph}), 2-layer KT-GNN eval "
-                                   f"forward F={args.feat} hidden={args.hidden} C={args.classes} (4 AdaptedConv)",
+            "config": {"workload": f"{wl['name']} N={N} E'={Eprime}, 2-layer KT-GNN eval fwd F={args.feat} hidden={args.hidden} C={args.classes}",
                        "parallelism": par, "csr_build_ms": csr_ms},
             "hidden_conv_edges_per_sec": e_local * world / (agg_ms * 1e-3),
-            "roofline": {"bound": "hbm", "kernel": f"agg_wide_kernel<D={args.hidden}> (hidden AdaptedConv aggregation)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args, world), "bytes_per_launch": bytes_launch, "ms_per_launch": agg_ms},
+            "roofline": roof,
+            "output_checksums": {"what": "fp64 sums of the three log-prob outputs of the timed forward" +
+                                         (" (this rank's rows)" if use_dist else ""),
+                                 "base": checksums[0], "target": checksums[1], "target_hat": checksums[2]},
         }
         if knn is not None:
             out["knn"] = knn
         if train is not None:
             out["train"] = train
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not use_dist and not args.no_cpu:
+            out["cpu_baseline"], parity = cpu_baseline(args, model, wl, gpu_out)
+            if parity is not None:
+                out["parity"] = parity
+            if args.config == "c4":
+                out["cpu_baseline_torch"] = cpu_baseline_torch(args, model)
             if knn is not None:
-                out["knn"]["cpu_baseline"] = knn_cpu_baseline(args.knn_n)
+                out["knn"]["cpu_baseline"], out["knn"]["cpu_baseline_gemm"] = knn_cpu_baselines(args.knn_n)
         out["eager_ms_per_step"] = ms_step
         out["config"]["execution"] = "eager launches"
-    printed = False
     if not args.no_graph_replay:
-        printed = not graph_phase(args, runner, barrier, use_dist, dev, rank, out, 4 * Eprime)
-    if rank == 0 and not printed:
+        graph_phase(args, runner, barrier, use_dist, dev, rank, world, out, 4 * Eprime)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.barrier()

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import ops
 from .data import Data
 
-__all__ = ["BridgeScorer", "add_topk_sim_cross_domain_edges", "add_topk_sim_within_domain_edges",
+__all__ = ["BridgeScorer", "add_topk_sim_cross_domain_edges", "add_topk_sim_within_domain_edges", "sharded_cosine_topk_edges",
            "merge_graphs", "pair_enumeration", "check_added_edges_cross_domain_validity",
            "check_added_edges_within_domain_validity", "align_e_sim_to_edges", "reorder", "eval_bridged_Graph",
            "eval_homophily", "gen_bridged_graph"]
@@ -159,14 +159,25 @@ class BridgeScorer:
         return (A.contiguous(), B.contiguous(), scale.contiguous(), shift.contiguous(),
                 s["lin_self.4.weight"].reshape(-1).contiguous(), float(s["lin_self.4.bias"].reshape(-1)[0].item()))
 
-    def topk(self, z_cand, z_query, k):
-        """-> (idx [Nq,k] int64, probs [Nq,k] fp32, n_fallback) ; rows sorted by (score desc, idx asc)."""
+    def topk(self, z_cand, z_query, k, rank=0, world=1, group=None):
+        """-> (idx [Nq,k] int64, probs [Nq,k] fp32, n_fallback) ; rows sorted by (score desc, idx asc).
+        world > 1: this rank scores the query rows `shard_range(Nq, rank, world)` only (-> [Nq/world, k]
+        tables); the per-node halves of the scorer are evaluated on the rank's slice of the candidate rows and made whole
+        by ONE all_gather; no cross-rank merge of top-k lists is needed under row partitioning."""
+        from .dist import all_gather_rows, shard_range
+        same = z_query is z_cand
+        clo, chi = shard_range(z_cand.shape[0], rank, world)
+        qlo, qhi = shard_range(z_query.shape[0], rank, world)
+        zc, zq = z_cand[clo:chi], z_query[qlo:qhi]
         if self.sim_mode == "mlp":
-            A, B, scale, shift, w2, b2 = self.mlp_terms(z_cand, z_query)
-            return ops.mlp_pair_topk(A, B, scale, shift, w2, b2, k, apply_sigmoid=True)
-        qc = ops.l2_normalize_rows(self.cosine_q(z_cand))
-        qq = qc if z_query is z_cand else ops.l2_normalize_rows(self.cosine_q(z_query))
-        return ops.cosine_topk(qq, qc, k, apply_sigmoid=True)
+            A, _, scale, shift, w2, b2 = self.mlp_terms(zc, zq[:0])
+            _, B, _, _, _, _ = self.mlp_terms(zc[:0], zq)
+            A = all_gather_rows(A, group, world)
+            return ops.mlp_pair_topk(A.contiguous(), B, scale, shift, w2, b2, k, apply_sigmoid=True)
+        qc_local = ops.l2_normalize_rows(self.cosine_q(zc))
+        qc = all_gather_rows(qc_local, group, world)
+        qq = qc[qlo:qhi] if same else ops.l2_normalize_rows(self.cosine_q(zq))
+        return ops.cosine_topk(qq.contiguous(), qc.contiguous(), k, apply_sigmoid=True)
 
     # ---- reference-shaped entry points (explicit pair lists; small inputs / API parity) ---------
     def pair_probs(self, z1, z2, idx1, idx2):
@@ -196,14 +207,51 @@ def _homophily(y_from, y_to, edge_index):
     return (same.sum() / lab.sum()).item() if int(lab.sum()) > 0 else float("nan")
 
 
+def sharded_cosine_topk_edges(q_local, cand_local, k, rank=0, world=1, group=None, query_base=0, events=None,
+                              apply_sigmoid=True, backend=None):
+    """The cosine kNN bridge on raw embeddings, sharded by query rows (main_bridged_graph.py:45-68 is a loop over query
+    batches -- the natural shard).  `q_local` = this rank's query rows (global ids start at `query_base`),
+    `cand_local` = this rank's slice of the candidate rows: each rank normalises its slice, ONE all_gather makes the
+    candidates whole (rank order = global candidate id order), every rank scores its queries against all of them.
+    -> (coalesced edge_index of this rank's queries with GLOBAL ids, idx [nq,k], probs [nq,k], n_fallback).
+    The union of the ranks' edge lists, coalesced, is the single-rank edge list (tests/test_dist_gloo.py).
+    `events` = (start, end) HIP events recorded around the top-k call.  `backend`: namespace providing l2_normalize_rows /
+    cosine_topk / topk_edges / coalesce (default: the HIP ops; the CPU gloo test of this host logic injects the oracle)."""
+    from .dist import all_gather_rows
+    be = ops if backend is None else backend
+    qn = be.l2_normalize_rows(q_local)
+    cn = all_gather_rows(be.l2_normalize_rows(cand_local), group, world)
+    if events is not None:
+        events[0].record()
+    idx, val, nfb = be.cosine_topk(qn, cn.contiguous(), k, apply_sigmoid=apply_sigmoid)
+    if events is not None:
+        events[1].record()
+    ei = be.coalesce(be.topk_edges(idx, cand_base=0, query_base=int(query_base)))
+    return ei, idx, val, nfb
+
+
+def gather_edges(edge_index, group=None, world=None, backend=None):
+    """per-rank coalesced edge lists -> the global coalesced list on every rank (only when one `Data` must be
+    materialised; partitioned by destination is the layout half B wants anyway)."""
+    from .dist import all_gather_rows
+    be = ops if backend is None else backend
+    allv = all_gather_rows(edge_index.t().contiguous(), group, world).t().contiguous()
+    return be.coalesce(allv)
+
+
 def add_topk_sim_cross_domain_edges(data_src, data_tar, model, epsilon=0.5, k=3, batch_size=1000,
-                                    z_src=None, z_tar=None, verbose=True):
+                                    z_src=None, z_tar=None, verbose=True, rank=0, world=1, group=None):
     """main_bridged_graph.py:33-75.  Returns (coalesced edge_index [2,E] (row0 = source id, row1 =
     target id), e_sim_mat [Nt,k] sigmoid probs in top-k order, idx_src_mat [Nt,k] int64,
-    probs_clf_src [Ns,C], probs_clf_tar [Nt,C]); all CUDA tensors."""
+    probs_clf_src [Ns,C], probs_clf_tar [Nt,C]); all CUDA tensors.
+    world > 1: the target (query) rows are sharded over the ranks (`BridgeScorer.topk`), the [Nt/world, k] tables are
+    all-gathered, and every rank returns the same 5-tuple as a single-rank call."""
     z_src = model.encode_source(data_src) if z_src is None else z_src.to(model.device).float()
     z_tar = model.encode_target(data_tar) if z_tar is None else z_tar.to(model.device).float()
-    idx, probs, _ = model.topk(z_src.contiguous(), z_tar.contiguous(), k)
+    idx, probs, _ = model.topk(z_src.contiguous(), z_tar.contiguous(), k, rank=rank, world=world, group=group)
+    if world > 1:
+        from .dist import all_gather_rows
+        idx, probs = all_gather_rows(idx, group, world), all_gather_rows(probs, group, world)
     edge_index_added = ops.topk_edges(idx)                                     # :61-68
     if verbose and hasattr(data_src, "y") and hasattr(data_tar, "y"):
         ys, yt = data_src.y.to(model.device), data_tar.y.to(model.device)

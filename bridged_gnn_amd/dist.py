@@ -29,7 +29,38 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["partition_nodes", "PartitionPlan", "HaloExchange", "PartitionedKTGNN"]
+__all__ = ["partition_nodes", "PartitionPlan", "HaloExchange", "PartitionedKTGNN", "all_gather_rows", "shard_range"]
+
+
+def shard_range(n, rank, world):
+    """contiguous shard [lo, hi) of n rows for `rank` of `world` (the kNN bridge's query / candidate split)"""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def all_gather_rows(t, group=None, world=None, always=False):
+    """Row blocks of (possibly) different heights, one per rank -> their concatenation in rank order on every rank:
+    one tiny all_gather of the heights + ONE all_gather of the padded payload (RCCL: direct full mesh over xGMI, every
+    peer pair its own link).  The kNN bridge's only collective (`all_gather` of q_cand).  A gloo group
+    with CUDA tensors (several ranks rehearsing on one GPU) stages the payload through the host."""
+    if not dist.is_initialized() or ((world if world is not None else dist.get_world_size(group)) == 1 and not always):
+        return t            # `always`: issue the collectives even at world size 1 (smoke-tests the RCCL calls)
+    world = dist.get_world_size(group)
+    host = t.is_cuda and dist.get_backend(group) == "gloo"
+    work = t.cpu() if host else t.contiguous()
+    h = torch.tensor([work.shape[0]], dtype=torch.int64, device=work.device)
+    hs = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(hs, h, group=group)
+    heights = [int(v.item()) for v in hs]
+    hmax = max(heights)
+    pad = work
+    if work.shape[0] < hmax:
+        pad = torch.zeros((hmax,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+        pad[: work.shape[0]] = work
+    out = torch.empty((world * hmax,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if any(v != hmax for v in heights):
+        out = torch.cat([out[r * hmax: r * hmax + heights[r]] for r in range(world)], dim=0)
+    return out.to(t.device) if host else out
 
 
 def partition_nodes(central_mask, world, scheme="domain_blocks"):

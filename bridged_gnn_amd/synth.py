@@ -7,7 +7,7 @@ regenerate identical inputs; only arrays are produced, callers move them to the 
 """
 import numpy as np
 
-__all__ = ["bridged_graph", "sync_rd_intra", "gaussian_embeddings", "random_multigraph"]
+__all__ = ["bridged_graph", "sync_rd_intra", "twitter_standin", "gaussian_embeddings", "random_multigraph", "edge_hash"]
 
 
 def _local_or_uniform(rng, dst_rel, lo_domain, n_domain, cluster, p_local):
@@ -94,6 +94,62 @@ def sync_rd_intra(n=10000, feat=64, homophily=0.7, deg=10, k_cross=20, seed=0):
     mask = np.zeros(n, dtype=bool)
     mask[:ns] = True
     return x, ei, y.astype(np.int64), mask
+
+
+def _cosine_topk_f64(x_query, x_cand, k, chunk=2048):
+    """Exact cosine top-k on the host in float64 (rank: score desc, index asc).  float64 keeps the selected SETS the same
+    on every BLAS / CPU (neighbouring scores of N(0,1) features differ by >> 1e-15), which float32 GEMMs would not."""
+    qn = x_query.astype(np.float64)
+    qn /= np.maximum(np.linalg.norm(qn, axis=1, keepdims=True), 1e-12)
+    cn = x_cand.astype(np.float64)
+    cn /= np.maximum(np.linalg.norm(cn, axis=1, keepdims=True), 1e-12)
+    import torch                                   # CPU torch: threaded float64 GEMM + top-k (numpy's argpartition took 50 s)
+    out = np.empty((qn.shape[0], k), dtype=np.int64)
+    cnt = torch.from_numpy(np.ascontiguousarray(cn.T))
+    for s in range(0, qn.shape[0], chunk):
+        sim = torch.from_numpy(qn[s:s + chunk]) @ cnt
+        ps, part = torch.topk(sim, k, dim=1)
+        ps, part = ps.numpy(), part.numpy()
+        order = np.lexsort((part, -ps), axis=1)
+        out[s:s + chunk] = np.take_along_axis(part, order, axis=1)
+    return out
+
+
+def twitter_standin(n_src=581, n_tar=20230, feat=300, n_random=450_000, k_within=6, k_cross=20, seed=0):
+    """C3 stand-in for the absent Twitter_Graph bridged graph (shape from the reference's loader and recipe:
+    F=300 `dataset_ktgnn.py:81-82`, k_within=6 / k_cross=20 / hidden 128 / `--to_undirected` `run.sh:5-7`, original edges
+    undirected `datasets.py:24-29`; the node / edge counts are the survey's unverified shape hint).  Node order
+    [sources ; targets]; features i.i.d. N(0,1); `n_random` directed random edges over ALL nodes (intra + inter domain;
+    ~0.9 M once undirected) + cosine kNN bridge edges on the raw features (from = neighbour, to = query): `k_within`
+    same-domain neighbours per node (self matches kept, as in the reference, Appendix B-3) and `k_cross` source
+    neighbours per target node.  The caller makes it undirected (`ToUndirected`).
+    Returns (x fp32 [N,feat], edge_index int64 [2,E], y int64 [N], central_mask bool [N])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = n_src + n_tar
+    x = rng.standard_normal((n, feat), dtype=np.float32)
+    y = rng.integers(0, 2, size=n).astype(np.int64)
+    src_parts = [rng.integers(0, n, size=n_random)]
+    dst_parts = [rng.integers(0, n, size=n_random)]
+    for lo, m in ((0, n_src), (n_src, n_tar)):
+        if k_within > 0 and m > 0:
+            top = _cosine_topk_f64(x[lo:lo + m], x[lo:lo + m], min(k_within, m))
+            src_parts.append(lo + top.reshape(-1))
+            dst_parts.append(np.repeat(np.arange(lo, lo + m, dtype=np.int64), top.shape[1]))
+    if k_cross > 0 and n_src > 0 and n_tar > 0:
+        top = _cosine_topk_f64(x[n_src:], x[:n_src], min(k_cross, n_src))
+        src_parts.append(top.reshape(-1))
+        dst_parts.append(np.repeat(np.arange(n_src, n, dtype=np.int64), top.shape[1]))
+    ei = np.stack([np.concatenate(src_parts), np.concatenate(dst_parts)]).astype(np.int64)
+    mask = np.zeros(n, dtype=bool)
+    mask[:n_src] = True
+    return x, ei, y, mask
+
+
+def edge_hash(edge_index, num_nodes):
+    """Order-independent 61-bit checksum of an edge multiset (fixtures store it so a regenerated graph can be checked)."""
+    key = edge_index[0].astype(np.uint64) * np.uint64(num_nodes) + edge_index[1].astype(np.uint64)
+    key = (key ^ (key >> np.uint64(29))) * np.uint64(0x9E3779B97F4A7C15)      # wraps mod 2^64
+    return int(np.bitwise_xor.reduce(key) & np.uint64((1 << 61) - 1)) ^ int(edge_index.shape[1])
 
 
 def gaussian_embeddings(n, d=128, seed=0):

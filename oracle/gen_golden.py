@@ -16,7 +16,13 @@ Fixtures:
   knn_gauss.npz          G4(iii): raw Gaussian d=128 cosine (Similar_noTrans), Ns=20k, Nt=2k
   sage_encoder_v1.npz    8(f) rank 3: v1 GraphEncoder (2x SAGEConv, mean aggr) outputs on random graphs
   filters_office_a2d.npz 8(f) rank 2: check_added_edges_{cross,within}_domain_validity in/out (office A->D)
+Round 2 (run alone with `--only c3,layers,a4,assembly`; the sections above are untouched and still reproduce bit for bit):
+  ktgnn_c3.npz           BASELINE config 3: KTGNN_no_complement(300,2,2,128,use_bn) eval forward on synth.twitter_standin
+  ktgnn_layers.npz       layer_num = 1 (KTGNN.py:344-347) and layer_num = 3 (:348-358) eval forwards on a small graph
+  a4_office_a2d.npz      a4 glue: v2 encoders / class probs / get_probs_{cross,within}_domain on enumerated pairs, PairNorm modes
+  assembly_office_a2d.npz  merge_graphs (main_bridged_graph.py:163-193) and reorder (:195-222) outputs on the office pieces
 """
+import argparse
 import os
 import sys
 
@@ -56,9 +62,147 @@ def randomize_bn(module, gen):
             m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
 
 
+def office_pieces(MD, SData, tag, norm_mode="None"):
+    """(shipped graph, source Data, target Data, loaded Adversarial_Learner_v2, its state_dict, ns, nt) for an office pair"""
+    name = {"a2d": "office_amazon2dslr", "a2w": "office_amazon2webcam"}[tag]
+    dd = load_bridged_graph(os.path.join(REF, f"data_bridged_graph/{name}_bridged_graph.dat"))
+    cmk = dd.central_mask
+    ns = int(cmk.sum())
+    nt = dd.x.shape[0] - ns
+    loops = lambda n: torch.arange(n).unsqueeze(0).repeat(2, 1)
+    ds = SData(x=dd.x[:ns], edge_index=loops(ns), y=dd.y[:ns].clone(), train_mask=dd.train_mask[:ns])
+    dt = SData(x=dd.x[ns:], edge_index=loops(nt), y=dd.y[ns:].clone(),
+               train_mask=dd.train_mask[ns:], val_mask=dd.val_mask[ns:], test_mask=dd.test_mask[ns:])
+    ds_ctor = SData(x=ds.x, edge_index=ds.edge_index, y=torch.clamp(ds.y, min=0))
+    ds_ctor.y[0] = 30
+    dt_ctor = SData(x=dt.x, edge_index=dt.edge_index, y=torch.clamp(dt.y, min=0))
+    dt_ctor.y[0] = 30
+    sim = MD.Adversarial_Learner_v2(ds_ctor, dt_ctor, dim_hidden=128, num_layer=2, use_norm=True, source_clf=True,
+                                    norm_mode=norm_mode, norm_scale=1.0, sim_mode="mlp", backbone="mlp")
+    sd = torch.load(os.path.join(REF, f"ckpt/model_AdvLearner_{name}_best.ckpt"), map_location="cpu", weights_only=True)
+    sim.load_state_dict(sd, strict=True)
+    sim.eval()
+    return dd, ds, dt, sim, sd, ns, nt
+
+
+def round2_sections(KT, MD, BG, want):
+    from torch_geometric.data import Data as SData
+    from torch_geometric.utils import to_undirected as s_to_undirected
+
+    if want("c3"):
+        print("[C3] KTGNN on the Twitter stand-in (F=300, hidden=128)")
+        xs, ei_s, ys, ms = synth.twitter_standin(seed=0)
+        n = xs.shape[0]
+        ei_u = s_to_undirected(torch.from_numpy(ei_s), num_nodes=n)
+        torch.manual_seed(3)
+        model = KT.KTGNN_no_complement(300, 2, 2, 128, root_weight=False, use_bn=True, dim_share=300, need_complement=False)
+        randomize_bn(model, torch.Generator().manual_seed(9))
+        model.eval()
+        data = SData(x=torch.from_numpy(xs), edge_index=ei_u, y=torch.from_numpy(ys), central_mask=torch.from_numpy(ms))
+        with torch.no_grad():
+            lb, lt, lth, _ = model(data)
+            emb = model.get_emb(data)
+        rows = np.unique(np.concatenate([np.arange(0, 581, 4), np.arange(581, n, 16)]))
+        save("ktgnn_c3.npz", rows=rows, logp_base=lb.numpy()[rows], logp_target=lt.numpy()[rows],
+             logp_target_hat=lth.numpy()[rows], emb_rows=emb.numpy()[rows],
+             sums=np.array([lb.double().sum().item(), lt.double().sum().item(), lth.double().sum().item()]),
+             n_edges_undirected=np.int64(ei_u.shape[1]), edge_hash=np.int64(synth.edge_hash(ei_s, n)),
+             **sd_np(model, "sd."))
+
+    if want("layers"):
+        print("[a15] layer_num in {1, 3}")
+        xs, ei_s, ys, ms = synth.sync_rd_intra(n=1500, feat=32, homophily=0.7, deg=6, k_cross=8, seed=5)
+        ei_u = s_to_undirected(torch.from_numpy(ei_s), num_nodes=1500)
+        data = SData(x=torch.from_numpy(xs), edge_index=ei_u, y=torch.from_numpy(ys), central_mask=torch.from_numpy(ms))
+        out = {}
+        # layer_num = 1 (KTGNN.py:344-347): convs = [AdaptedConv(dim_in, num_classes)] feeding clf_* built for `hidden`
+        # inputs -> only consistent when hidden == num_classes, and bns stays empty -> use_bn must be False
+        torch.manual_seed(11)
+        m1 = KT.KTGNN_no_complement(32, 4, 1, 4, root_weight=False, use_bn=False, dim_share=32, need_complement=False)
+        randomize_bn(m1, torch.Generator().manual_seed(12))
+        m1.eval()
+        torch.manual_seed(13)
+        m3 = KT.KTGNN_no_complement(32, 3, 3, 32, root_weight=False, use_bn=True, dim_share=32, need_complement=False)
+        randomize_bn(m3, torch.Generator().manual_seed(14))
+        m3.eval()
+        with torch.no_grad():
+            for tag, m in (("l1", m1), ("l3", m3)):
+                lb, lt, lth, _ = m(data)
+                out.update({f"{tag}.logp_base": lb.numpy(), f"{tag}.logp_target": lt.numpy(), f"{tag}.logp_target_hat": lth.numpy(),
+                            f"{tag}.emb": m.get_emb(data).numpy()})
+                out.update(sd_np(m, f"{tag}.sd."))
+        save("ktgnn_layers.npz", **out)
+
+    if want("a4"):
+        print("[a4] v2 encoders / get_probs_* glue on office A->D")
+        dd, ds, dt, sim, sd, ns, nt = office_pieces(MD, SData, "a2d")
+        rng = np.random.default_rng(41)
+        P = 600
+        c_i1, c_i2 = torch.from_numpy(rng.integers(0, ns, P)), torch.from_numpy(rng.integers(0, nt, P))
+        s_i1, s_i2 = torch.from_numpy(rng.integers(0, ns, P)), torch.from_numpy(rng.integers(0, ns, P))
+        t_i1, t_i2 = torch.from_numpy(rng.integers(0, nt, P)), torch.from_numpy(rng.integers(0, nt, P))
+        with torch.no_grad():
+            pc, pcs, pct, zs, zt = sim.get_probs_cross_domain(ds, dt, c_i1, c_i2, return_representation=True)   # models.py:1132-1142
+            pws, pws_clf = sim.get_probs_within_domain(ds, s_i1, s_i2, domain="source")                         # :1122-1131
+            pwt, pwt_clf = sim.get_probs_within_domain(dt, t_i1, t_i2, domain="target")
+        assert np.array_equal(zs.numpy(), np.load(os.path.join(OUT, "knn_office_a2d.npz"))["z_src"])
+        arrs = dict(cross_idx1=c_i1.numpy(), cross_idx2=c_i2.numpy(), cross_probs=pc.numpy(), probs_clf_src=pcs.numpy(),
+                    probs_clf_tar=pct.numpy(),
+                    src_idx1=s_i1.numpy(), src_idx2=s_i2.numpy(), src_probs=pws.numpy(), src_probs_clf=pws_clf.numpy(),
+                    tar_idx1=t_i1.numpy(), tar_idx2=t_i2.numpy(), tar_probs=pwt.numpy(), tar_probs_clf=pwt_clf.numpy())
+        # PairNorm modes (models.py:29-64): the same weights under each mode (PairNorm has no parameters)
+        for mode in ("PN", "PN-SI", "PN-SCS"):
+            _, ds2, dt2, sim2, _, _, _ = office_pieces(MD, SData, "a2d", norm_mode=mode)
+            with torch.no_grad():
+                z2s = sim2.source_learner.backbone(ds2.x, ds2.edge_index)
+                z2t, _ = sim2.target_learner.encode(dt2)
+            arrs[f"z_src_{mode}"] = z2s.numpy()[::8]
+            arrs[f"z_tar_{mode}"] = z2t.numpy()[::2]
+        for k, v in sd.items():      # encoder weights (the scorer's sim_net.* and the reference's z are in knn_office_a2d.npz)
+            if k.startswith(("source_learner.backbone.", "target_learner.equavilent_trans_layer.", "target_learner.encoder.")):
+                arrs["sd." + k] = v.numpy()
+        save("a4_office_a2d.npz", **arrs)
+
+    if want("assembly"):
+        print("[a9 / f4] merge_graphs + reorder on the office A->D pieces")
+        import copy
+        dd, ds, dt, sim, sd, ns, nt = office_pieces(MD, SData, "a2d")
+        g = np.load(os.path.join(OUT, "knn_office_a2d.npz"))
+        ec = torch.from_numpy(g["cross_edge_index"].astype(np.int64))
+        es = torch.from_numpy(g["within_src_edge_index"].astype(np.int64))
+        et = torch.from_numpy(g["within_tar_edge_index"].astype(np.int64))
+        rng = np.random.default_rng(43)
+        # "original" edges of the two domains: random, with duplicates and self loops (the office loaders use self loops only)
+        ds.edge_index = torch.from_numpy(np.concatenate([rng.integers(0, ns, (2, 3000)), np.tile(np.arange(ns), (2, 1))], axis=1))
+        dt.edge_index = torch.from_numpy(np.concatenate([rng.integers(0, nt, (2, 700)), np.tile(np.arange(nt), (2, 1))], axis=1))
+        merged = BG.merge_graphs(ds, dt, copy.deepcopy(ec), es, et)                                   # :163-193 (mutates arg :170)
+        arrs = dict(ei_src=ds.edge_index.numpy().astype(np.int32), ei_tar=dt.edge_index.numpy().astype(np.int32),
+                    merged_edge_index=merged.edge_index.numpy().astype(np.int32), merged_y=merged.y.numpy().astype(np.int16),
+                    merged_train=merged.train_mask.numpy(), merged_val=merged.val_mask.numpy(),
+                    merged_test=merged.test_mask.numpy(), merged_central=merged.central_mask.numpy(),
+                    merged_x_col0=merged.x[:, 0].numpy())
+        perm = rng.permutation(ns + nt)
+        orig_src, orig_tar = perm[:ns], perm[ns:]
+        m_src = {int(o): i for i, o in enumerate(orig_src)}          # orig id -> local index (utils.py:58-63)
+        m_tar = {int(o): i for i, o in enumerate(orig_tar)}
+        ro = BG.reorder(copy.deepcopy(merged), ds, m_src, m_tar)                                      # :195-222
+        arrs.update(orig_src=orig_src.astype(np.int32), orig_tar=orig_tar.astype(np.int32),
+                    reordered_edge_index=ro.edge_index.numpy().astype(np.int32), reordered_y=ro.y.numpy().astype(np.int16),
+                    reordered_train=ro.train_mask.numpy(), reordered_val=ro.val_mask.numpy(), reordered_test=ro.test_mask.numpy(),
+                    reordered_central=ro.central_mask.numpy(), reordered_x_col0=ro.x[:, 0].numpy())
+        save("assembly_office_a2d.npz", **arrs)
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma list of round-2 sections (c3,layers,a4,assembly); default: everything")
+    only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     KT, MD, BG = ref_import.import_reference()
+    if only:
+        round2_sections(KT, MD, BG, lambda t: t in only)
+        print("done")
+        return
     import torch_geometric
     from torch_geometric.data import Data as SData
     from torch_geometric.utils import coalesce as s_coalesce, to_undirected as s_to_undirected
@@ -277,6 +421,7 @@ def main():
     vals, idxs = torch.cat(vals), torch.cat(idxs)
     save("knn_gauss.npz", ns=np.int64(ns), nt=np.int64(nt), d=np.int64(dimq), k=np.int64(k),
          seed_src=np.int64(21), seed_tar=np.int64(22), e_sim=vals.numpy(), idx=idxs.numpy().astype(np.int32))
+    round2_sections(KT, MD, BG, lambda t: True)
     print("done")
 
 

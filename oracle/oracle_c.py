@@ -102,3 +102,37 @@ def mlp_topk(A_cand, B_query, scale, shift, w2, b2, k):
                        C.c_int64(B.shape[0]), C.c_int64(A.shape[0]), C.c_int32(A.shape[1]), C.c_int32(k),
                        _p(idx), _p(val))
     return val, idx
+
+
+def ktgnn_forward_eval(x, rowptr, col, mask, sd, use_bn=True, return_emb=False):
+    """KTGNN_no_complement.forward in eval mode (models/KTGNN.py:401-435, need_complement=False) composed from the C
+    routines above over a by-destination CSR (oracle_np.dst_csr); same result as oracle_np.ktgnn_forward_eval, which
+    is the one pinned to the reference's golden vectors (tests/test_oracle_c.py checks the two against each other).
+    -> (logp_base, logp_target, logp_target_hat[, emb])."""
+    from . import oracle_np as O
+
+    def conv(xx, prefix):
+        p = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        hs2t, ht2s = adaptedconv_transform(xx, mask, p)
+        return adaptedconv_aggregate(ht2s, hs2t, p["a_f_t2s.weight"], p["a_f_s2t.weight"], rowptr, col, mask)
+
+    def bn(h, prefix, eps=1e-5):
+        b = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        return ((h - b["running_mean"]) / np.sqrt(b["running_var"] + np.float32(eps)) * b["weight"] + b["bias"]).astype(np.float32)
+
+    h = _f32(x)
+    i = 0
+    while f"convs.{i}.lin_s.weight" in sd:                                     # :418-430
+        h = conv(h, f"convs.{i}.")
+        if use_bn:
+            h = bn(h, f"bns.{i}.")
+        h = np.maximum(h, 0).astype(np.float32)
+        i += 1
+    a = conv(h, "clf_base.")                                                   # :432
+    t = h @ _f32(sd["clf_transformer.0.weight"]).T + sd["clf_transformer.0.bias"]
+    t = np.maximum(bn(t, "clf_transformer.1."), 0).astype(np.float32)
+    t = (t @ _f32(sd["clf_transformer.3.weight"]).T + sd["clf_transformer.3.bias"]).astype(np.float32)
+    b = conv(t, "clf_target.")                                                 # :433
+    c = conv(h, "clf_target.")                                                 # :434
+    out = (O.log_softmax(a), O.log_softmax(c), O.log_softmax(b))               # :435 (base, target, target_hat)
+    return out + (h,) if return_emb else out

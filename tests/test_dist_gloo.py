@@ -155,3 +155,81 @@ def test_partition_schemes():
     assert (np.diff(o[:10]) >= 0).all() and (np.diff(o[10:]) >= 0).all()
     o2 = partition_nodes(m, 3, "contiguous")
     assert (np.diff(o2) >= 0).all() and set(o2) == {0, 1, 2}
+
+
+# ------------------------------------------------------------------------------------------------ kNN bridge, sharded
+class _OracleKnnBackend:
+    """compute stand-in for the HIP ops in the CPU test of the sharded kNN HOST logic (sharding, the all_gather of the
+    candidates, global ids, edge assembly): the oracle's canonical routines on CPU tensors"""
+
+    @staticmethod
+    def l2_normalize_rows(q):
+        return torch.from_numpy(OC.l2_normalize_rows(q.numpy()))
+
+    @staticmethod
+    def cosine_topk(qn, cn, k, apply_sigmoid=True):
+        val, idx = OC.cosine_topk(qn.numpy(), cn.numpy(), k)
+        v = O.sigmoid_f32(val) if apply_sigmoid else val.astype(np.float32)
+        return torch.from_numpy(idx), torch.from_numpy(v), torch.zeros(1, dtype=torch.int32)
+
+    @staticmethod
+    def topk_edges(idx, cand_base=0, query_base=0):
+        nq, k = idx.shape
+        to = torch.arange(nq, dtype=torch.int64).repeat_interleave(k) + query_base
+        return torch.stack([idx.reshape(-1) + cand_base, to])
+
+    @staticmethod
+    def coalesce(ei):
+        return torch.from_numpy(O.coalesce(ei.numpy()))
+
+
+def _knn_problem():
+    from bridged_gnn_amd import synth
+    q = synth.gaussian_embeddings(301, 32, seed=3)          # 301 / 1000: uneven shards at world 2 and 3
+    c = synth.gaussian_embeddings(1000, 32, seed=4)
+    c[500:520] = c[100:120]                                  # exact duplicates: ties are broken by the lower index
+    return q, c
+
+
+def _knn_worker(rank, world, port, q_out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bridged_gnn_amd import bridge
+        from bridged_gnn_amd.dist import shard_range
+        q, c = _knn_problem()
+        qlo, qhi = shard_range(q.shape[0], rank, world)
+        clo, chi = shard_range(c.shape[0], rank, world)
+        ei, idx, val, _ = bridge.sharded_cosine_topk_edges(torch.from_numpy(q[qlo:qhi]), torch.from_numpy(c[clo:chi]), 7,
+                                                           rank=rank, world=world, query_base=qlo, backend=_OracleKnnBackend)
+        full = bridge.gather_edges(ei, world=world, backend=_OracleKnnBackend)
+        q_out.put((rank, ei.numpy(), idx.numpy(), val.numpy(), full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_knn_union_equals_single_rank(world):
+    """row N2 / SURVEY 8(e): query-row shards + ONE all_gather of the candidates; the union of the per-rank edge lists
+    (and the gathered list every rank ends up with) is bit-identical to the single-rank coalesced edge list."""
+    from bridged_gnn_amd import bridge
+    q, c = _knn_problem()
+    one_ei, one_idx, one_val, _ = bridge.sharded_cosine_topk_edges(torch.from_numpy(q), torch.from_numpy(c), 7,
+                                                                   backend=_OracleKnnBackend)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    qq = ctx.Queue()
+    procs = [ctx.Process(target=_knn_worker, args=(r, world, port, qq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([qq.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(np.concatenate([r[2] for r in res]), one_idx.numpy())          # [Nq/P, k] slices in rank order
+    assert np.array_equal(np.concatenate([r[3] for r in res]), one_val.numpy())
+    union = O.coalesce(np.concatenate([r[1] for r in res], axis=1))
+    assert np.array_equal(union, one_ei.numpy())
+    assert sum(r[1].shape[1] for r in res) == one_ei.shape[1]                            # no edge on two ranks
+    for r in res:
+        assert np.array_equal(r[4], one_ei.numpy())                                      # gather_edges: whole on every rank

@@ -155,3 +155,139 @@ def test_partitioned_forward_real_processes_sharing_the_gpu(world):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(s["n_halo"] > 0 for _, _, s in res)
+
+
+# ------------------------------------------------------------------------------------------------ kNN bridge, sharded
+def _knn_gpu_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bridged_gnn_amd import bridge, synth
+        from bridged_gnn_amd.dist import shard_range
+        qe, ce = synth.gaussian_embeddings(3001, 128, seed=3), synth.gaussian_embeddings(9000, 128, seed=4)
+        ce[4000:4040] = ce[100:140]                              # exact duplicates
+        qlo, qhi = shard_range(3001, rank, world)
+        clo, chi = shard_range(9000, rank, world)
+        ei, idx, val, nfb = bridge.sharded_cosine_topk_edges(_t(qe[qlo:qhi]), _t(ce[clo:chi]), 20, rank=rank, world=world,
+                                                             query_base=qlo)
+        full = bridge.gather_edges(ei, world=world)
+        q.put((rank, ei.cpu().numpy(), idx.cpu().numpy(), full.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_knn_real_processes_sharing_the_gpu(world):
+    """row N2: the production kernels behind `bridge.sharded_cosine_topk_edges` in REAL ranks (gloo group, candidates
+    all-gathered through the host because RCCL refuses two ranks per device): the union of the per-rank edge lists and the
+    gathered list are bit-identical to the single-rank result and to the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    from bridged_gnn_amd import bridge, synth
+    from oracle import oracle_c as OC
+    from oracle import oracle_np as O
+    qe, ce = synth.gaussian_embeddings(3001, 128, seed=3), synth.gaussian_embeddings(9000, 128, seed=4)
+    ce[4000:4040] = ce[100:140]
+    one_ei, one_idx, _, _ = bridge.sharded_cosine_topk_edges(_t(qe), _t(ce), 20)
+    _, ref_idx = OC.cosine_topk(OC.l2_normalize_rows(qe), OC.l2_normalize_rows(ce), 20)
+    assert np.array_equal(one_idx.cpu().numpy(), ref_idx)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    qq = ctx.Queue()
+    procs = [ctx.Process(target=_knn_gpu_worker, args=(r, world, port, qq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([qq.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(np.concatenate([r[2] for r in res]), ref_idx)
+    assert np.array_equal(O.coalesce(np.concatenate([r[1] for r in res], axis=1)), one_ei.cpu().numpy())
+    for r in res:
+        assert np.array_equal(r[3], one_ei.cpu().numpy())
+
+
+def test_sharded_scorer_topk_slices_equal_the_whole(golden):
+    """`BridgeScorer.topk(rank, world)` (mlp scorer, office ckpt): the rank slices of the [Nq, k] tables, computed one
+    after the other in this process without a process group (world_size 1 collectives are identities), tile the
+    single-rank tables when the candidate terms are taken whole."""
+    from bridged_gnn_amd.bridge import BridgeScorer
+    from bridged_gnn_amd.dist import shard_range
+    from conftest import sub
+    kf = golden("knn_office_a2d.npz")
+    sd = {"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(kf, "sim.").items()}
+    sc = BridgeScorer(sd, DEV)
+    zs, zt = _t(kf["z_src"]), _t(kf["z_tar"])
+    idx, probs, _ = sc.topk(zs, zt, 20)
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(zt.shape[0], r, world)
+            i, p, _ = sc.topk(zs, zt[lo:hi].contiguous(), 20)          # a rank's query slice against ALL candidates
+            parts.append((i, p))
+        assert torch.equal(torch.cat([i for i, _ in parts]), idx)
+        # the per-node GEMM of the query terms runs on another batch shape (another library kernel): last-ulp differences
+        assert torch.allclose(torch.cat([p for _, p in parts]), probs, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL at world size 1
+def _nccl_world1_worker(port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        from bridged_gnn_amd import synth
+        from bridged_gnn_amd.data import Data
+        from bridged_gnn_amd.dist import PartitionedKTGNN, all_gather_rows
+        ei, mask = synth.bridged_graph(3000, 2000, 4, 8, 6000, cluster=128, p_local=0.8, seed=4)
+        m = _model(64, 64, 3)
+        g = torch.Generator(device=DEV).manual_seed(1)
+        x = torch.randn(5000, 64, device=DEV, generator=g)
+        with torch.no_grad():
+            ref = m(Data(x=x, edge_index=_t(ei), central_mask=_t(mask)))[:3]
+        res = {}
+        for cache in (True, False):
+            pk = PartitionedKTGNN(m, ei, mask, 0, 1, DEV, always_communicate=True, cache_input_halo=cache)
+            xl = x[pk.owned_global].contiguous()
+            with torch.no_grad():
+                out = pk.forward(xl)
+                res[f"eager_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out, ref))
+                # the bench's second phase: the forward INCLUDING its RCCL calls captured into a HIP graph and replayed
+                for _ in range(2):
+                    pk.forward(xl)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                    got = pk.forward(xl)
+                for _ in range(3):
+                    gr.replay()
+                torch.cuda.synchronize()
+                res[f"replay_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(got, ref))
+        # the kNN bridge's collective on device buffers
+        t = torch.randn(37, 128, device=DEV)
+        res["all_gather_rows"] = bool(torch.equal(all_gather_rows(t, always=True), t))
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_calls_at_world_size_1_eager_and_captured():
+    """The RCCL entry points the 8-GPU run depends on -- `init_process_group("nccl", device_id=...)`, the fused all-reduce
+    of the domain sums, `all_to_all_single` with (empty) uneven splits on device buffers, and HIP-graph capture of a
+    forward that contains them -- executed for real with backend nccl at world size 1 (`always_communicate=True`), in a
+    child process so the process group cannot leak into other tests."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert all(res.values()), res

@@ -1,0 +1,272 @@
+"""GPU: parity cases added in round 2 -- BASELINE config 3 (Twitter stand-in, F=300 / hidden=128), layer_num in {1, 3},
+the a4 glue (v2 encoders, PairNorm, get_probs_*), merge_graphs / reorder against reference-generated fixtures, the
+full-size C4 forward with real attention on sampled rows, and the two advisor findings (CSR cache identity, eval-mode
+backward through clf_transformer).  Float bar 1e-5 relative (tests/conftest.py:assert_close) unless a test says why not."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, sub
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+from oracle import oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _load_model(sd, *ctor, **kw):
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    model = KTGNN_no_complement(*ctor, **kw)
+    model.load_state_dict({n: torch.from_numpy(np.asarray(v)) for n, v in sd.items()}, strict=True)
+    return model.to(DEV).eval()
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+def test_ktgnn_c3_twitter_standin_golden(golden):
+    """BASELINE config 3: Twitter_Graph stand-in (581 S + 20 230 T, F=300, ~0.9 M random + kNN edges, undirected),
+    2-layer KT-GNN hidden 128 (`run.sh:5-7`); expected outputs from the reference's own KTGNN.py (oracle/gen_golden.py).
+    Din=300 is outside the W-stationary transform's envelope -> the tiled fp32-MFMA GEMM kernel runs here."""
+    from bridged_gnn_amd import synth, utils
+    from bridged_gnn_amd.data import Data
+    k = golden("ktgnn_c3.npz")
+    x, ei, y, m = synth.twitter_standin(seed=0)
+    n = x.shape[0]
+    assert synth.edge_hash(ei, n) == int(k["edge_hash"]), "stand-in graph differs from the one the fixture was made on"
+    und = utils.to_undirected(_t(ei), n)
+    assert und.shape[1] == int(k["n_edges_undirected"])
+    model = _load_model(sub(k, "sd."), 300, 2, 2, 128, root_weight=False, use_bn=True, dim_share=300)
+    data = Data(x=_t(x), edge_index=und, y=_t(y), central_mask=_t(m))
+    with torch.no_grad():
+        lb, lt, lth, _ = model(data)
+        emb = model.get_emb(data)
+    rows = k["rows"]
+    assert_close(emb.cpu().numpy()[rows, :128], k["emb_rows"], what="get_emb")
+    assert_close(lb.cpu().numpy()[rows], k["logp_base"], what="logp_base")
+    assert_close(lt.cpu().numpy()[rows], k["logp_target"], what="logp_target")
+    assert_close(lth.cpu().numpy()[rows], k["logp_target_hat"], what="logp_target_hat")
+    sums = np.array([t.double().sum().item() for t in (lb, lt, lth)])
+    assert np.allclose(sums, k["sums"], rtol=1e-5)
+    # the HIP-graph replay of the same forward (what bench.py --config c3 times) returns the same tensors
+    replay = model.graphed(data)
+    g = replay()
+    assert torch.allclose(g[0], lb, rtol=1e-6, atol=1e-6) and torch.allclose(g[2], lth, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ layer_num
+@pytest.mark.parametrize("tag,ctor,use_bn", [("l1", (32, 4, 1, 4), False), ("l3", (32, 3, 3, 32), True)])
+def test_ktgnn_layer_num_1_and_3(golden, tag, ctor, use_bn):
+    """KTGNN.py:344-358: the layer_num == 1 branch (one conv straight to `num_classes` columns feeding clf_*; hidden ==
+    num_classes, no BatchNorm) and the three-layer chain, where a conv's column-sum epilogue feeds the next conv."""
+    from bridged_gnn_amd import synth, utils
+    from bridged_gnn_amd.data import Data
+    k = golden("ktgnn_layers.npz")
+    x, ei, y, m = synth.sync_rd_intra(n=1500, feat=32, homophily=0.7, deg=6, k_cross=8, seed=5)
+    und = utils.to_undirected(_t(ei), 1500)
+    model = _load_model(sub(k, f"{tag}.sd."), *ctor, root_weight=False, use_bn=use_bn, dim_share=32)
+    assert len(model.convs) == {"l1": 1, "l3": 2}[tag]
+    data = Data(x=_t(x), edge_index=und, y=_t(y), central_mask=_t(m))
+    with torch.no_grad():
+        lb, lt, lth, _ = model(data)
+        emb = model.get_emb(data)
+    assert_close(emb.cpu().numpy()[:, :k[f"{tag}.emb"].shape[1]], k[f"{tag}.emb"], what="get_emb")
+    assert_close(lb.cpu().numpy(), k[f"{tag}.logp_base"], what="logp_base")
+    assert_close(lt.cpu().numpy(), k[f"{tag}.logp_target"], what="logp_target")
+    assert_close(lth.cpu().numpy(), k[f"{tag}.logp_target_hat"], what="logp_target_hat")
+
+
+def test_layer_num_1_with_bn_fails_like_the_reference():
+    """the reference indexes an empty `bns` list (KTGNN.py:425) when layer_num == 1 and use_bn: IndexError there and here"""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    ei, mask = synth.random_multigraph(100, 500, seed=1)
+    model = KTGNN_no_complement(8, 4, 1, 4, use_bn=True, dim_share=8).to(DEV).eval()
+    with pytest.raises(IndexError), torch.no_grad():
+        model(Data(x=torch.randn(100, 8, device=DEV), edge_index=_t(ei), central_mask=_t(mask)))
+
+
+# ------------------------------------------------------------------------------------------------ a4 glue
+def test_a4_encoders_pairnorm_and_get_probs_vs_reference(golden):
+    """models/models.py:29-64 (PairNorm), :880-893 (MLP.forward), :1092-1096 (encode), :1122-1142 (get_probs_*): the
+    BridgeScorer built from the shipped office A->D checkpoint against the reference's outputs on the shipped features."""
+    from bridged_gnn_amd.bridge import BridgeScorer
+    from bridged_gnn_amd.data import Data
+    f, g, kf = golden("a4_office_a2d.npz"), golden("office_a2d_graph.npz"), golden("knn_office_a2d.npz")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(f, "sd.").items()}
+    sd.update({"source_learner.sim_net." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(kf, "sim.").items()})
+    ns = int(kf["n_src"])
+    ds, dt = Data(x=_t(g["x"][:ns])), Data(x=_t(g["x"][ns:]))
+    sc = BridgeScorer(sd, DEV)
+    assert sc.version == "v2" and sc.sim_mode == "mlp"
+    zs, zt = sc.encode_source(ds), sc.encode_target(dt)
+    assert_close(zs.cpu().numpy(), kf["z_src"], what="encode_source")
+    assert_close(zt.cpu().numpy(), kf["z_tar"], what="encode_target")
+    for mode in ("PN", "PN-SI", "PN-SCS"):
+        scm = BridgeScorer(sd, DEV, norm_mode=mode)
+        # PairNorm divides by a norm of O(10..100)-term fp32 sums whose order differs between torch-CPU and the GPU
+        assert_close(scm.encode_source(ds).cpu().numpy()[::8], f[f"z_src_{mode}"], rtol=2e-5, atol_scale=2e-6, what=f"z_src {mode}")
+        assert_close(scm.encode_target(dt).cpu().numpy()[::2], f[f"z_tar_{mode}"], rtol=2e-5, atol_scale=2e-6, what=f"z_tar {mode}")
+    i1, i2 = _t(f["cross_idx1"]), _t(f["cross_idx2"])
+    p, pcs, pct, z1, z2 = sc.get_probs_cross_domain(ds, dt, i1, i2, return_representation=True)
+    assert p.shape == (600, 1) and torch.equal(z1, zs) and torch.equal(z2, zt)
+    assert_close(p.cpu().numpy(), f["cross_probs"], what="get_probs_cross_domain")
+    assert_close(pcs.cpu().numpy(), f["probs_clf_src"], what="probs_clf_src")
+    assert_close(pct.cpu().numpy(), f["probs_clf_tar"], what="probs_clf_tar")
+    p, pc = sc.get_probs_within_domain(ds, _t(f["src_idx1"]), _t(f["src_idx2"]), domain="source")
+    assert_close(p.cpu().numpy(), f["src_probs"], what="get_probs_within_domain(source)")
+    assert_close(pc.cpu().numpy(), f["src_probs_clf"], what="within source clf probs")
+    p, pc = sc.get_probs_within_domain(dt, _t(f["tar_idx1"]), _t(f["tar_idx2"]), domain="target")
+    assert_close(p.cpu().numpy(), f["tar_probs"], what="get_probs_within_domain(target)")
+    assert_close(pc.cpu().numpy(), f["tar_probs_clf"], what="within target clf probs")
+    # the pair entry point and the streaming top-k kernel agree on the winners' probabilities
+    idx, probs, _ = sc.topk(zs, zt[:64], 20)
+    q = torch.arange(64, device=DEV).repeat_interleave(20)
+    again = sc.pair_probs(zs, zt[:64], idx.reshape(-1), q)
+    assert_close(again.cpu().numpy(), probs.reshape(-1).cpu().numpy(), what="pair_probs vs top-k values")
+
+
+# ------------------------------------------------------------------------------------------------ a9 / f4
+def test_merge_graphs_and_reorder_vs_reference_fixture(golden):
+    """main_bridged_graph.py:163-193 and :195-222 on the GPU against the reference's own outputs (bit-exact)."""
+    from bridged_gnn_amd import bridge
+    from bridged_gnn_amd.data import Data
+    a, kf, g = golden("assembly_office_a2d.npz"), golden("knn_office_a2d.npz"), golden("office_a2d_graph.npz")
+    ns = int(kf["n_src"])
+    x, y = g["x"], g["y"]
+    i64 = lambda v: _t(v.astype(np.int64))
+    ds = Data(x=_t(x[:ns]), edge_index=i64(a["ei_src"]), y=_t(y[:ns]), train_mask=_t(g["train_mask"][:ns]))
+    dt = Data(x=_t(x[ns:]), edge_index=i64(a["ei_tar"]), y=_t(y[ns:]), train_mask=_t(g["train_mask"][ns:]),
+              val_mask=_t(g["val_mask"][ns:]), test_mask=_t(g["test_mask"][ns:]))
+    ec = i64(kf["cross_edge_index"])
+    ec_before = ec.clone()
+    merged = bridge.merge_graphs(ds, dt, ec, i64(kf["within_src_edge_index"]), i64(kf["within_tar_edge_index"]))
+    assert torch.equal(ec, ec_before), "the cross-edge argument must not be modified (the reference mutates it, :170)"
+    assert np.array_equal(merged.edge_index.cpu().numpy(), a["merged_edge_index"])
+    for key, ref in (("y", "merged_y"), ("train_mask", "merged_train"), ("val_mask", "merged_val"), ("test_mask", "merged_test"),
+                     ("central_mask", "merged_central")):
+        assert np.array_equal(getattr(merged, key).cpu().numpy(), a[ref]), key
+    assert np.array_equal(merged.x[:, 0].cpu().numpy(), a["merged_x_col0"])
+    m_src = {int(o): i for i, o in enumerate(a["orig_src"])}              # the reference's dict form (utils.py:58-63)
+    ro = bridge.reorder(merged, ds, m_src, torch.from_numpy(a["orig_tar"].astype(np.int64)))   # and the tensor form
+    assert np.array_equal(ro.edge_index.cpu().numpy(), a["reordered_edge_index"])
+    for key, ref in (("y", "reordered_y"), ("train_mask", "reordered_train"), ("val_mask", "reordered_val"),
+                     ("test_mask", "reordered_test"), ("central_mask", "reordered_central")):
+        assert np.array_equal(getattr(ro, key).cpu().numpy(), a[ref]), key
+    assert np.array_equal(ro.x[:, 0].cpu().numpy(), a["reordered_x_col0"])
+
+
+# ------------------------------------------------------------------------------------------------ advisor findings
+def test_csr_cache_is_keyed_by_tensor_identity_and_version():
+    """the reference-parity call `conv(x, edge_index, e1, e2, mask)` caches its CSR: a second edge_index of the same
+    shape that the caching allocator puts on the freed block, or an in-place edit, must not reuse the stale CSR."""
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.ktgnn import AdaptedConv
+    n, E = 500, 4000
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    conv = AdaptedConv(16, 8, root_weight=False).to(DEV).eval()
+    x = torch.randn(n, 16, device=DEV)
+    mask = _t(rng.random(n) < 0.5)
+
+    def expect(ei):
+        with torch.no_grad():
+            return conv(x, None, central_mask=mask, csr=ops.build_dst_csr(ei, n, rewrite_self_loops=False))
+    ptrs = []
+    for trial in range(3):
+        ei = _t(rng.integers(0, n, (2, E)))
+        ptrs.append(ei.data_ptr())
+        with torch.no_grad():
+            got = conv(x, ei, None, None, mask)
+        assert torch.equal(got, expect(ei)), f"stale CSR on trial {trial}"
+        del ei                                         # the next tensor of the same size lands on the same block
+    with torch.no_grad():
+        ei = _t(rng.integers(0, n, (2, E)))
+        a = conv(x, ei, None, None, mask)
+        ei[0, :100] = (ei[0, :100] + 1) % n            # in-place edit: same object, same pointer, new version
+        b = conv(x, ei, None, None, mask)
+    assert torch.equal(b, expect(ei)) and not torch.equal(a, b)
+
+
+def test_eval_mode_backward_reaches_clf_transformer():
+    """model.eval() with grad enabled (frozen-BN fine-tuning, input attribution): every parameter -- the two Linears of
+    clf_transformer included -- and the input get the gradients of the CPU fp64 autograd oracle."""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    n, feat, hidden, C = 500, 12, 64, 3              # hidden 64: inside the raw W-stationary kernel's envelope
+    ei, mask = synth.random_multigraph(n, 4000, frac_src=0.5, seed=5)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((n, feat)).astype(np.float32)
+    w = [rng.standard_normal((n, C)) for _ in range(3)]
+    torch.manual_seed(4)
+    model = KTGNN_no_complement(feat, C, 2, hidden, use_bn=True, dim_share=feat)
+    g = torch.Generator().manual_seed(2)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    xg = _t(x).requires_grad_(True)
+    out = model(Data(x=xg, edge_index=_t(ei), central_mask=_t(mask)))
+    sum((o * _t(wi).float()).sum() for o, wi in zip(out[:3], w)).backward()
+    # oracle: the reference's op sequence in fp64 on the CPU
+    ref = KTGNN_no_complement(feat, C, 2, hidden, use_bn=True, dim_share=feat)
+    ref.load_state_dict(sd0)
+    ref = ref.double().eval()
+    mo = torch.from_numpy(mask)
+    e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    conv = lambda c, xx: OT.adaptedconv(xx, mo, e1, e2, dict(c.named_parameters()))
+    h = torch.relu(ref.bns[0](conv(ref.convs[0], xo)))
+    outs = (torch.log_softmax(conv(ref.clf_base, h), 1), torch.log_softmax(conv(ref.clf_target, h), 1),
+            torch.log_softmax(conv(ref.clf_target, ref.clf_transformer(h)), 1))
+    sum((o * torch.from_numpy(wi)).sum() for o, wi in zip(outs, w)).backward()
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    for o, r in zip(out[:3], outs):
+        assert rel(o.detach().cpu().double(), r.detach()) < 2e-5
+    assert rel(xg.grad.cpu().double(), xo.grad) < 2e-4, "dL/dx"
+    refp = dict(ref.named_parameters())
+    for name, prm in model.named_parameters():
+        assert prm.grad is not None, f"{name} got no gradient"
+        assert rel(prm.grad.cpu().double(), refp[name].grad) < 2e-4, name
+
+
+# ------------------------------------------------------------------------------------------------ C4 at full size
+def test_c4_full_size_forward_real_attention_vs_oracle():
+    """The bench's own model (seeded weights, non-trivial BatchNorm) on the bench's own 1M-node / 21M-edge graph, real
+    attention: the hidden conv output (BN + ReLU epilogue on) and the three log-prob heads against a full forward of the
+    C oracle -- strictly (1e-5) on >= 512 sampled destination rows of both domains including the max-degree rows, and
+    over ALL rows as well."""
+    import argparse
+    import bench
+    from bridged_gnn_amd.data import Data
+    args = argparse.Namespace(config="c4", nodes=1_000_000, edges=20_000_000, graph="local", feat=128, hidden=128, classes=2)
+    wl = bench.make_workload(args, torch.device(DEV))
+    model = bench.build_model(args, DEV)
+    ei, mask = wl["ei_np"], wl["mask_np"]
+    data = Data(x=wl["x"], edge_index=_t(ei), central_mask=_t(mask))
+    with torch.no_grad():
+        out = [t.cpu().numpy() for t in model(data)[:3]]
+        emb = model.get_emb(data).cpu().numpy()[:, :128]
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rowptr, col, _ = O.dst_csr(ei, mask)
+    assert int(rowptr[-1]) == 20_991_058
+    rb, rt, rth, remb = OC.ktgnn_forward_eval(wl["x"].cpu().numpy(), rowptr, col, mask, sd, return_emb=True)
+    deg = np.diff(rowptr)
+    n = mask.shape[0]
+    rows = np.unique(np.concatenate([np.arange(0, n, 1999), np.argsort(deg[: n // 2])[-64:], n // 2 + np.argsort(deg[n // 2:])[-64:],
+                                     np.argsort(deg)[:16]]))
+    assert rows.shape[0] >= 512 and mask[rows].sum() >= 200 and (~mask[rows]).sum() >= 200
+    for name, got, ref in (("hidden conv (BN+ReLU)", emb, remb), ("logp_base", out[0], rb), ("logp_target", out[1], rt),
+                           ("logp_target_hat", out[2], rth)):
+        assert_close(got[rows], ref[rows], what=f"{name}, sampled rows")
+        assert_close(got, ref, what=f"{name}, all rows")
+    # the checksums bench.py prints for the timed forward are those of this output
+    sums = [float(np.asarray(o, np.float64).sum()) for o in out]
+    assert np.allclose(sums, [float(np.asarray(r, np.float64).sum()) for r in (rb, rt, rth)], rtol=1e-6)

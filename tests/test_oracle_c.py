@@ -51,3 +51,17 @@ def test_c_mlp_topk_bit_exact_vs_numpy(golden):
     v_np, i_np = O.topk_rows(O.mlp_scores_canonical(A, B, scale, shift, w2, b2), 20)
     v_c, i_c = OC.mlp_topk(A, B, scale, shift, w2, b2, 20)
     assert np.array_equal(i_np, i_c) and np.array_equal(v_np, v_c)
+
+
+def test_c_ktgnn_forward_matches_numpy_and_golden(golden):
+    """the C composition of the whole eval forward (used for the full-size parity samples and bench.py's checksums)
+    against the numpy restatement and the reference's office golden"""
+    g, p, k = golden("office_a2d_graph.npz"), golden("partition_office.npz"), golden("ktgnn_office.npz")
+    sd = sub(k, "sd.")
+    rowptr, col, _ = O.dst_csr(p["ei_undirected"], g["central_mask"])
+    lb, lt, lth, emb = OC.ktgnn_forward_eval(g["x"], rowptr, col, g["central_mask"], sd, return_emb=True)
+    nb, nt, nth = O.ktgnn_forward_eval(g["x"], p["ei_undirected"], g["central_mask"], sd)
+    for a, b, c, what in ((lb, nb, k["logp_base"], "base"), (lt, nt, k["logp_target"], "target"), (lth, nth, k["logp_target_hat"], "target_hat")):
+        assert_close(a, b, what=f"C vs numpy {what}")
+        assert_close(a, c, what=f"C vs reference {what}")
+    assert_close(emb[::8], k["emb_rows"], what="emb")
