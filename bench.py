@@ -321,7 +321,7 @@ def knn_bench(args, dev, rank=0, world=1):
     issued = pairs_rank * 256 * pieces / tk / 1e12
     return {"workload": f"C5 cosine kNN {n}x{n} d=128 k=20 (normalise + score + top-k + coalesce)"
                         + (f", query rows sharded x{world}, one all_gather of the candidates" if world > 1 else ""),
-            "pairs_per_s": pairs / t, "ms": t * 1e3, "fallback_rows": int(nfb.item()), "edges_this_rank": int(ei.shape[1]),
+            "pairs_per_s": pairs / t, "ms": t * 1e3, "fallback_rows": int(nfb[0].item()), "precise_pass_rows": int(nfb[1].item()), "edges_this_rank": int(ei.shape[1]),
             "roofline": {"bound": "mfma", "kernel": "bgnn_cosine_topk_f32 (pass 1 shortlist on bf16 MFMA + fp64 refine + fallback)",
                          "achieved": issued, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / BF16_MFMA_PEAK_TFLOPS,
                          "traffic": None, "ms_per_launch": tk * 1e3, "bf16_products_per_pair_term": pieces,

@@ -10,6 +10,21 @@
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+// hipFuncSetAttribute is per (function, device): cached per device id so that a second device driven by the same
+// process gets its own call (one process normally drives one GPU; residency / CU-count caches elsewhere assume that all
+// devices of the process are the same model).
+constexpr int BGNN_MAX_DEVICES = 16;
+static inline hipError_t bgnn_set_max_dynamic_lds(const void* fn, int bytes, int* done /*[BGNN_MAX_DEVICES], zero-initialised*/) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const bool cached = dev >= 0 && dev < BGNN_MAX_DEVICES;
+  if (cached && __atomic_load_n(&done[dev], __ATOMIC_ACQUIRE) == bytes + 1) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && cached) __atomic_store_n(&done[dev], bytes + 1, __ATOMIC_RELEASE);
+  return e;
+}
+
 static inline bool bgnn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t bgnn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -297,8 +297,9 @@ extern "C" int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float
   const int pa = (p + 31) / 32;
 #define BGNN_GRAM(PA)                                                                                                  \
   do {                                                                                                                 \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_partial_kernel<PA>),         \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+    static int attr_done[BGNN_MAX_DEVICES];                                                                            \
+    const hipError_t attr = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(gram_partial_kernel<PA>),           \
+                                                     160 * 1024 - 1024, attr_done);                                    \
     if (attr != hipSuccess) return (int)attr;                                                                          \
     hipLaunchKernelGGL(gram_partial_kernel<PA>, dim3(nblk), dim3(256), sh, st, g);                                     \
   } while (0)

@@ -3,18 +3,17 @@
 // pair_enumeration models/models.py:265-282, scorers :124-130 (cosine) and :944-954 (mlp),
 // Tensor.topk call sites main_bridged_graph.py:60,:104).
 //
-// Three passes (see include/bgnn.h for the contract):
-//   1. stream every candidate against a block of queries, fp32 scores (cosine: v_mfma_f32_32x32x2_f32
-//      tiles, candidates = A operand so that one lane holds 16 scores of ONE query -> a single
-//      threshold register per lane; mlp: VALU), keep a KP-entry shortlist per query in LDS
-//      (threshold filter + rare wave-wide bitonic compaction);
-//   2. re-score the shortlist in CANONICAL arithmetic (fp64, feature-index order), rank by
-//      (score desc, index asc), and prove by an error-bound margin that the exact top-k lies inside
-//      the shortlist; unproven rows are queued;
-//   3. queued rows are re-done exhaustively in canonical arithmetic.
+// A cascade of filters with a proof at every stage (see include/bgnn.h for the contract):
+//   0. split: every fp32 embedding is split exactly into bf16 pieces hi + mid (+ rest); the largest L2 norms of the
+//      residuals are measured, which gives a RIGOROUS bound eps on |approximate score - exact score| for each product set;
+//   1. FAST pass: stream every candidate against a block of queries on the bf16 matrix cores with ONE piece per candidate
+//      (cand_hi . (query_hi [+ query_mid])), keep per query the candidates whose approximate score lies within 2 eps of the
+//      running k-th best (a sorted per-query buffer in LDS, threshold register per lane);
+//   2. refine: re-score the survivors in CANONICAL arithmetic (fp64, feature-index order), rank by (score desc, index asc)
+//      and prove  kth_exact > (best score any excluded candidate can have) + eps ; unproven rows are queued;
+//   3. PRECISE pass on the queued rows only: the same kernel with three piece products (eps ~ 5e-5) + refine;
+//   4. rows still unproven (exact ties across the boundary) are re-done exhaustively in canonical arithmetic.
 // Index results are therefore bit-identical to oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk.
-#include <cstdio>
-
 #include <cstdlib>
 #include "bgnn_common.h"
 
@@ -22,19 +21,21 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#ifndef KNN_CAND_PIECES
-#define KNN_CAND_PIECES 2
-#endif
-constexpr int CPIECES = KNN_CAND_PIECES;   // bf16 pieces per candidate value (3 = full fp32 significand, 2 = 2^-18)
-constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
-constexpr int WAVES = 4;
-constexpr int QPB = QPW * WAVES;   // queries per block
-constexpr int CT = 32;             // candidates per MFMA tile
 
-// ---- sortable keys: larger key = better (higher score, then LOWER candidate index) --------------
+constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
+constexpr int CT = 32;             // candidates per MFMA tile
+constexpr int MAX_SLOTS = 8;       // shortlists per query (blocks whose tile range touches one query block)
+constexpr int LDS_BYTES = 160 * 1024;
+#ifndef KNN_SCHED_NUM
+#define KNN_SCHED_NUM 3            // scheduled compactions at stream positions growing by (1 + NUM/8)
+#endif
+#ifndef KNN_SCHED_FREE
+#define KNN_SCHED_FREE 26          // ... of the buffers with fewer free slots than this
+#endif
+
+// ---- orderable score bits: larger uint = larger float ------------------------------------------
 __device__ __forceinline__ uint32_t ord_f32(float f) {
   uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -42,311 +43,322 @@ __device__ __forceinline__ uint32_t ord_f32(float f) {
 __device__ __forceinline__ float unord_f32(uint32_t o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
-__device__ __forceinline__ u64 make_key(float s, int32_t idx) {
-  return ((u64)ord_f32(s) << 32) | (u64)(0xFFFFFFFFu - (uint32_t)idx);
-}
-__device__ __forceinline__ int32_t key_idx(u64 k) { return (int32_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu)); }
-__device__ __forceinline__ float key_score(u64 k) { return unord_f32((uint32_t)(k >> 32)); }
-constexpr u64 KEY_EMPTY = 0ull;    // below every real key (ord(-inf) = 0x007FFFFF > 0)
+constexpr uint32_t ORD_EMPTY = 0u;      // below every real score (ord(-inf) = 0x007FFFFF)
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl_xor(lo, m);
-  hi = __shfl_xor(hi, m);
-  return ((u64)hi << 32) | lo;
+// ---- error bounds ------------------------------------------------------------------------------
+// Residual maxima written by the split kernels (ordered-uint atomicMax): [0] = max_c |c - c_hi|_2, [1] = max_c |c - c_hi - c_mid|_2,
+// [2] / [3] the same for the queries.  For unit vectors a, b (|a|, |b| <= 1 + 2^-20 after the fp32 normalisation):
+//   1 product  (ah.bh)                : a.b - ah.bh         = ra.b + ah.rb                 -> |.| <= Ra (1+g) + (1+g+Ra) Rb
+//   2 products (ah.bh + ah.bm)        : a.b - ah.(bh+bm)    = ra.b + ah.rrb                -> |.| <= Ra (1+g) + (1+g+Ra) Rbb
+//   3 products (+ am.bh)              : a.b - (..)          = am.bm + rra.b + (ah+am).rrb  -> |.| <= Ra Rb (1+u)^2.. + Raa (1+g) + (1+g+Raa) Rbb
+// (Cauchy-Schwarz on each term) plus the fp32 accumulation inside the MFMAs, counted as truncating: terms * 2^-23 * 1.01.
+struct EpsSrc { const uint32_t* mx; int d; };
+__device__ __forceinline__ float knn_eps(const EpsSrc& e, int nprod) {
+  const float g = 1e-6f, infl = 1.002f;            // norm slack; the residual norms were summed in fp32
+  const float Ra = unord_f32(e.mx[0]) * infl, Raa = unord_f32(e.mx[1]) * infl;
+  const float Rb = unord_f32(e.mx[2]) * infl, Rbb = unord_f32(e.mx[3]) * infl;
+  float eps;
+  if (nprod == 1) eps = Ra * (1.f + g) + (1.f + g + Ra) * Rb;
+  else if (nprod == 2) eps = Ra * (1.f + g) + (1.f + g + Ra) * Rbb;
+  else eps = Ra * Rb * 1.02f + Raa * (1.f + g) + (1.f + g + Raa) * Rbb;
+  eps += (float)(e.d * nprod) * 1.2e-7f * 1.01f;
+  return eps * 1.001f;
 }
 
-// wave-wide bitonic sort, DESCENDING, of 64*EPL keys (element e of lane l has global index l + 64*e)
-template <int EPL>
-__device__ __forceinline__ void wave_sort_desc(u64 (&v)[EPL], int lane) {
-  constexpr int NTOT = 64 * EPL;
-#pragma unroll
-  for (int k = 2; k <= NTOT; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64) {   // partner lives in the same lane (only EPL == 2, j == 64)
-        const int i0 = lane, i1 = lane + 64;
-        const bool desc = ((i0 & k) == 0);   // k == 128 here -> always true
-        u64 a = v[0], b = v[EPL - 1];
-        const bool sw = desc ? (a < b) : (a > b);
-        if (sw) { v[0] = b; v[EPL - 1] = a; }
-        (void)i1;
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int i = lane + 64 * e;
-          const u64 o = shfl_xor_u64(v[e], j);
-          const bool desc = ((i & k) == 0);
-          const bool lower = ((i & j) == 0);          // I am the lower index of the pair
-          // descending block: lower index keeps the max
-          const bool keep_max = (desc == lower);
-          v[e] = keep_max ? (v[e] > o ? v[e] : o) : (v[e] < o ? v[e] : o);
-        }
-      }
-    }
-  }
+extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];     // the dynamic LDS of every kernel of this file
+
+// wave-wide maximum of an unsigned value through DPP / swizzle moves (no LDS bpermute round trips)
+__device__ __forceinline__ uint32_t bgnn_wave_max_u32(uint32_t x) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));     // lane ^ 1
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));     // lane ^ 2
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));    // row_half_mirror
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));    // row_mirror
+  x = mx(x, (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F));                      // lane ^ 16
+  return mx(x, (uint32_t)__shfl_xor((int)x, 32));
 }
 
 // ---- per-wave shortlist state in LDS -----------------------------------------------------------
-// Per query: CAP buffer entries of which the best KP are "live"; the CAP-KP others absorb arrivals
-// between two compactions.  Per wave: a small QUEUE of (key, query) pairs.  Scores that beat the lane's
-// threshold register are only queued while tiles stream (ballot-prefix offsets, no atomics, bounded
-// time -> the block barrier is never held up by one wave's bookkeeping); the queue is drained in
-// batches of 64 (one LDS atomic round for the whole batch) every few tiles.
-#if defined(KNN_EXP) && (KNN_EXP == 8 || KNN_EXP == 9 || KNN_EXP == 10)
-__device__ unsigned long long g_knn_cnt[8];
-__device__ unsigned long long g_knn_blk[1024 * 3];
-#define KCOUNT(i, v) do { if (KNN_EXP == 8 && lane == 0) atomicAdd(&g_knn_cnt[i], (unsigned long long)(v)); } while (0)
-#else
-#define KCOUNT(i, v) do { } while (0)
-#endif
-#if defined(KNN_EXP) && KNN_EXP == 9
-#define KSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define KACC(i, a, b) do { if (lane == 0) tk.dbg[i] += (b) - (a); } while (0)
-#else
-#define KSTAMP(var)
-#define KACC(i, a, b) do { } while (0)
-#endif
-constexpr int QCAP = 128;                  // queue entries per wave
-#ifdef DRAIN_EVERY_OVERRIDE
-constexpr int DRAIN_EVERY = DRAIN_EVERY_OVERRIDE;
-#else
-constexpr int DRAIN_EVERY = 8;
-#endif             // tiles between unconditional drains (all waves drain together)
-
+// Per query: a buffer of CAP (ordered score, candidate) entries, a fill count and the admission threshold tau.  A score
+// that beats the lane's threshold register is inserted DIRECTLY: one returning LDS atomic on the query's count hands out
+// the slot (the two lanes that hold a query may insert at once), two stores fill it.  A full buffer is COMPACTED: the
+// k-th best score is bracketed by a bisection on the ordered score bits (ballot + popcount per step: scalar work, no
+// sorting network, no LDS traffic), the threshold becomes  max(old, k-th best - margin)  -- everything that can still
+// matter for a proof with error bound eps = margin / 2 -- or a KP-th-best bracket when more than KP entries lie above it,
+// and the kept entries are packed to the front by ballot prefix (their order is irrelevant).
+// Invariant: every candidate that was ever refused or dropped has an approximate score <= tau (tau never decreases).
 template <int CAPV, int KPV>
 struct WaveTopK {
-  static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
-  static_assert(KPV < CAPV && CAPV - KPV >= 2 && CAPV <= 128, "shortlist geometry");
-  static constexpr size_t BYTES = sizeof(u64) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW +
-                                  sizeof(u64) * QCAP + sizeof(int) * QCAP + 64;
-  u64* keys;                             // [QPW][CAP]
-  int* cnt;                              // [QPW]
-  float* tau;                            // [QPW]  current admission threshold (score of the KP-th best)
-  u64* qkey;                             // [QCAP] queued keys
-  int* qqry;                             // [QCAP] their query (0..31)
-  int qcount;                            // wave-uniform
-  unsigned long long* dbg;               // [8] cycle counters (diagnostic builds only)
+  static constexpr int CAP = CAPV, KP = KPV, EPL = CAPV / 64;
+  static_assert(CAPV == 64 || CAPV == 128, "one or two buffer entries per lane");
+  static_assert(KPV < CAPV, "slack between two compactions");
+  static constexpr size_t BYTES = 2 * sizeof(uint32_t) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW;
+  // the state is addressed as an OFFSET into the kernel's dynamic LDS (not as generic pointers): the accessors below
+  // keep the address space visible to the compiler across the noinline helpers (ds_* instead of flat_* accesses)
+  unsigned base;                         // byte offset of this wave's state in knn_smem
+  int k;                                 // wanted neighbours
+  float margin_abs, margin_rel;          // margin(a) = margin_abs + margin_rel * |a|
+  __device__ __forceinline__ uint32_t* skey() const { return reinterpret_cast<uint32_t*>(knn_smem + base); }            // [QPW][CAP] ord(score)
+  __device__ __forceinline__ uint32_t* sidx() const { return skey() + QPW * CAP; }                                      // [QPW][CAP] candidate
+  __device__ __forceinline__ int* cnt() const { return reinterpret_cast<int*>(sidx() + QPW * CAP); }                    // [QPW]
+  __device__ __forceinline__ float* tau() const { return reinterpret_cast<float*>(cnt() + QPW); }                       // [QPW]
 
-  __device__ __forceinline__ void carve(unsigned char* base) {
-    keys = reinterpret_cast<u64*>(base);
-    qkey = keys + QPW * CAP;
-    cnt = reinterpret_cast<int*>(qkey + QCAP);
-    tau = reinterpret_cast<float*>(cnt + QPW);
-    qqry = reinterpret_cast<int*>(tau + QPW);
-    dbg = reinterpret_cast<unsigned long long*>(qqry + QCAP);
+  __device__ __forceinline__ void carve(unsigned byte_offset) { base = byte_offset; }
+  __device__ __forceinline__ void init(int lane, float tau0) {          // tau0: the lane's query (lane & 31)
+    if (lane < QPW) { cnt()[lane] = 0; tau()[lane] = tau0; }
   }
-  __device__ __forceinline__ void kq_store(int q, int slot, u64 k) { keys[q * CAP + slot] = k; }
-  __device__ __forceinline__ void init(int lane) {
-    for (int t = lane; t < QPW * CAP; t += 64) keys[t] = KEY_EMPTY;
-    if (lane < QPW) { cnt[lane] = 0; tau[lane] = -INFINITY; }
-    qcount = 0;
+  // number of buffer entries of this wave's lanes (EPL per lane) whose ordered score exceeds the scalar pivot
+  __device__ __forceinline__ static int count_above(const uint32_t (&s)[EPL], uint32_t pivot) {
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(s[e] > pivot));
+    return c;
   }
-  // keep the best KP entries of query q (sorted descending), refresh tau.  Whole wave, uniform q.
+  // Compaction of query q's buffer (whole wave, uniform q).
   __device__ __forceinline__ void compact(int q, int lane) {
-    const int n = min(cnt[q], CAP);
-    if constexpr (EPL == 1) {
-      // rank by counting: every lane streams the query's CAP keys from LDS (same address in all lanes ->
-      // broadcast reads) and counts the larger ones; no shuffle network, ~3 VALU ops per key.
-      // Valid keys are unique (distinct candidate index) and all exceed KEY_EMPTY, so ranks of valid keys
-      // are a permutation of [0, n); slots >= n are never read.
-      const u64* kq = keys + q * CAP;
-      const u64 key = lane < n ? kq[lane] : KEY_EMPTY;
-      int rank = 0;
-      // batches of 16 keys (8 x ds_read_b128, independent, issued back to back), then 16 compares
-      static_assert(CAP % 8 == 0, "CAP multiple of 8");
+    const int n = min(cnt()[q], CAP);
+    const float tau_old = tau()[q];
+    uint32_t s[EPL], x[EPL];
+    uint32_t smax = ORD_EMPTY;
 #pragma unroll
-      for (int j0 = 0; j0 < CAP; j0 += 16) {
-        constexpr int NB = 16;
-        u64 kk[NB];
-#pragma unroll
-        for (int t = 0; t < NB; t += 2) {
-          if (j0 + t < CAP) {
-            const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(kq + j0 + t);
-            kk[t] = two.x; kk[t + 1] = two.y;
-          } else { kk[t] = KEY_EMPTY; kk[t + 1] = KEY_EMPTY; }
-        }
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-          const u64 kj = (j0 + t < n) ? kk[t] : KEY_EMPTY;
-          rank += (kj > key) ? 1 : 0;
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): all reads of the old order done before the scatter
-      if (lane < n) kq_store(q, rank, key);
-      if (lane < n && rank == KP - 1) tau[q] = unord_f32((uint32_t)(key >> 32));
-      if (lane == 0) cnt[q] = n < KP ? n : KP;
-    } else {
-      u64 v[EPL];
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const int i = lane + 64 * e;
-        v[e] = i < n ? keys[q * CAP + i] : KEY_EMPTY;
-      }
-      wave_sort_desc<EPL>(v, lane);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const int i = lane + 64 * e;
-        if (i < CAP) keys[q * CAP + i] = v[e];
-      }
-      constexpr int TL = (KP - 1) % 64, TE = (KP - 1) / 64;
-      const uint32_t kb = __shfl((uint32_t)(v[TE] >> 32), TL);
-      if (lane == 0) {
-        cnt[q] = n < KP ? n : KP;
-        tau[q] = (n >= KP) ? unord_f32(kb) : -INFINITY;
-      }
+    for (int e = 0; e < EPL; ++e) {
+      const int i = lane + 64 * e;
+      s[e] = i < n ? skey()[q * CAP + i] : ORD_EMPTY;          // empty slots carry 0 < ord(-inf)
+      x[e] = sidx()[q * CAP + i];
+      smax = s[e] > smax ? s[e] : smax;
     }
+    // bracket the `want`-th best: count(s > lo) >= want > count(s > hi)
+    auto bracket = [&](int want, uint32_t lo, uint32_t hi) {
+      for (int it = 0; it < 32 && hi - lo > 4096u; ++it) {     // 2^12 ordered steps of an fp32: < 2^-11 relative, far inside the margin
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const bool ge = count_above(s, mid) >= want;
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid;
+      }
+      return lo;                                               // the want-th best lies in (lo, hi]
+    };
+    const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgnn_wave_max_u32(smax));
+    const uint32_t lo0 = ord_f32(tau_old);                     // every buffered entry was admitted above tau_old
+    float tm = -INFINITY;
+    if (n >= k) {
+      const float a = unord_f32(bracket(k, lo0, hi0));         // a lower bound of the k-th best, tight to 2^-11
+      tm = a - (margin_abs + margin_rel * fabsf(a));
+    }
+    tm = fmaxf(tm, tau_old);
+    uint32_t tmo = ord_f32(tm);
+    int cm = count_above(s, tmo);
+    if (cm > KP) {                                  // wave-uniform, rare: more than KP candidates inside the margin
+      // raise the threshold to the smallest bracket end with at most KP entries above it
+      uint32_t lo = tmo, hi = hi0;                  // count(s > lo) > KP >= count(s > hi) = 0
+      for (int it = 0; it < 40 && hi - lo > 1u; ++it) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const bool gt = count_above(s, mid) > KP;
+        lo = gt ? mid : lo;
+        hi = gt ? hi : mid;
+      }
+      lo = hi;
+      tmo = lo;
+      tm = unord_f32(tmo);
+      cm = count_above(s, tmo);
+    }
+    int before = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const bool kp = s[e] > tmo;
+      const unsigned long long b = __ballot(kp);
+      if (kp) {
+        const int pos = before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        skey()[q * CAP + pos] = s[e];
+        sidx()[q * CAP + pos] = x[e];
+      }
+      before += __popcll(b);
+    }
+    if (lane == 0) { cnt()[q] = cm; tau()[q] = tm; }
   }
 };
 
 template <class TK>
 __device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
-  KSTAMP(c0);
   while (qmask) {
     const int qq = __ffs(qmask) - 1;
     qmask &= qmask - 1;
-    KCOUNT(4, 1);
     tk.compact(qq, lane);
   }
-  KSTAMP(c1);
-  KACC(5, c0, c1);
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the new cnt / tau are visible to the wave's next LDS reads
 }
 
-// Move the queued pairs into the per-query buffers, 64 at a time; full buffers are compacted and the
-// affected pairs re-checked against the raised threshold.
+// Lanes in `pend` hold an arrival (ordered score so, candidate cand, query q) that found its buffer full: compact the
+// buffers involved and insert what still beats the raised thresholds.  Rare path (a buffer fills every ~30 arrivals).
 template <class TK>
-__device__ __noinline__ void drain_queue(TK tk, int n, int lane) {
+__device__ __noinline__ void insert_overflow(TK tk, bool pend, uint32_t so, uint32_t cand, int q, int lane) {
   constexpr int CAP = TK::CAP;
-#if defined(KNN_EXP) && KNN_EXP == 6
-  return;                                           // timing experiment: queueing only
-#endif
-  KCOUNT(3, 1);
-  KSTAMP(d0);
-  for (int base = 0; base < n; base += 64) {
-    const int e = base + lane;
-    const bool have = e < n;
-    const u64 key = have ? tk.qkey[e] : KEY_EMPTY;
-    const int qi = have ? tk.qqry[e] : 0;
-    bool pend = have && key_score(key) > tk.tau[qi];
-    for (int guard = 0; guard < 64; ++guard) {
-      if (pend) {
-        const int slot = atomicAdd(&tk.cnt[qi], 1);
-        if (slot < CAP) { tk.keys[qi * CAP + slot] = key; pend = false; }
-      }
-      unsigned long long over = __ballot(pend);
-      if (!over) break;
-      unsigned int qmask = 0;                       // distinct queries that overflowed
-      while (over) {
-        const int lead = __ffsll((long long)over) - 1;
-        const int qsel = __builtin_amdgcn_readlane(qi, lead);
-        qmask |= 1u << qsel;
-        over &= ~__ballot(pend && qi == qsel);
-      }
-#if defined(KNN_EXP) && KNN_EXP == 7
-      if (lane < 32 && ((qmask >> lane) & 1)) tk.cnt[lane] = TK::KP;   // timing experiment: no compaction work
-#else
-      compact_rows(tk, qmask, lane);
-#endif
-      pend = pend && key_score(key) > tk.tau[qi];
+  for (int guard = 0; guard < 64; ++guard) {
+    unsigned long long over = __ballot(pend);
+    if (!over) break;
+    unsigned int qmask = 0;                         // distinct queries among the pending lanes
+    while (over) {
+      const int lead = __ffsll((long long)over) - 1;
+      const int qsel = __builtin_amdgcn_readlane(q, lead);
+      qmask |= 1u << qsel;
+      over &= ~__ballot(pend && q == qsel);
+    }
+    compact_rows(tk, qmask, lane);
+    pend = pend && unord_f32(so) > tk.tau()[q];
+    if (pend) {
+      const int slot = atomicAdd(&tk.cnt()[q], 1);
+      if (slot < CAP) { tk.skey()[q * CAP + slot] = so; tk.sidx()[q * CAP + slot] = cand; pend = false; }
     }
   }
-  KSTAMP(d1);
-  KACC(4, d0, d1);
 }
 
-__device__ __forceinline__ float select16(const f32x16& acc, int r) {
-  float v = acc[0];
-#pragma unroll
-  for (int i = 1; i < 16; ++i) v = (r == i) ? acc[i] : v;
-  return v;
-}
-
-// Offer the 16 scores a lane holds (one query q = lane&31, candidates cbase + cand(r)).
+// Offer the 16 scores a lane holds (one query q = lane & 31, candidates cbase + cand(r, h)).  One ballot per accumulator
+// register: a register nobody beats the threshold with costs a compare and a scalar branch; an arrival costs one
+// returning LDS atomic and two stores for all lanes of that register at once -- no per-lane bit masks, no runtime
+// register select, no queue.
 template <class TK>
-__device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int lane, float& tau,
-                                           bool force_drain) {
+__device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int cand_lo, int lane, float& tau) {
+  constexpr int CAP = TK::CAP;
   const int q = lane & 31, h = lane >> 5;
   if (cbase + CT > Nc) {                            // last (partial) tile only: mask candidates >= Nc
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (cbase + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) acc[r] = -INFINITY;
   }
-  float mx = acc[0];
+  float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-#if defined(KNN_EXP) && KNN_EXP == 4
-  if (__any(mx > tau)) asm volatile("" ::"v"(acc[3]));
-  return;                                         // timing experiment: fast-path test only
-#endif
-  if (__any(mx > tau)) {
-    uint32_t m = 0;
+  for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+  mx = fmaxf(mx, acc[15]);
+  if (!__any(mx > tau)) return;
+  int* const my_cnt = &tk.cnt()[q];
+  uint32_t* const my_row = tk.skey() + q * CAP;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (acc[r] > tau) ? (1u << r) : 0u;
-    while (true) {                                  // one queued score per lane and round, lowest register first
-      const bool pend = m != 0;
-      const unsigned long long b = __ballot(pend);
-      if (!b) break;
-      if (pend) {
-        const int r = __ffs(m) - 1;
-        const int off = tk.qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        tk.qkey[off] = make_key(select16(acc, r), cbase + (r & 3) + 8 * (r >> 2) + 4 * h);
-        tk.qqry[off] = q;
-        m &= m - 1;
+  for (int r = 0; r < 16; ++r) {
+    const bool hit = acc[r] > tau;
+    if (__any(hit)) {                               // wave-uniform
+      const uint32_t so = ord_f32(acc[r]);
+      const uint32_t cand = (uint32_t)(cand_lo + cbase + (r & 3) + 8 * (r >> 2) + 4 * h);
+      bool pend = hit;
+      if (hit) {
+        const int slot = atomicAdd(my_cnt, 1);
+        if (slot < CAP) { my_row[slot] = so; my_row[QPW * CAP + slot] = cand; pend = false; }
       }
-      tk.qcount += __popcll(b);
-      if (tk.qcount > QCAP - 64) {                  // wave-uniform: the next round might not fit
-        drain_queue(tk, tk.qcount, lane);
-        tk.qcount = 0;
-        tau = tk.tau[q];
-        uint32_t keep = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) keep |= (acc[r] > tau) ? (1u << r) : 0u;
-        m &= keep;
+      if (__any(pend)) {                            // a buffer is full
+        insert_overflow(tk, pend, so, cand, q, lane);
+        tau = tk.tau()[q];
       }
     }
   }
-  if (force_drain && tk.qcount > 0) {
-    drain_queue(tk, tk.qcount, lane);
-    tk.qcount = 0;
-    tau = tk.tau[q];
-  }
 }
 
-// final: sort each query's buffer and emit the best KP (score, idx) pairs, descending
+// final: every buffer trimmed to its threshold, then the (score, candidate) lists and the thresholds go to the workspace
 template <class TK>
-__device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, int64_t Nq,
-                                                float* __restrict__ sl_score, int32_t* __restrict__ sl_idx,
-                                                int split, int nsplit) {
+__device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, int64_t nq, float* __restrict__ sl_score,
+                                                int32_t* __restrict__ sl_idx, float* __restrict__ sl_tau, int slot, int nslots,
+                                                uint32_t cand_lo = 0) {
   constexpr int CAP = TK::CAP, KP = TK::KP, EPL = TK::EPL;
-  if (tk.qcount > 0) { drain_queue(tk, tk.qcount, lane); tk.qcount = 0; }
   compact_rows(tk, 0xFFFFFFFFu, lane);
   for (int q = 0; q < QPW; ++q) {
     const int64_t gq = q0 + q;
-    if (gq < Nq) {
+    if (gq < nq) {
+      const int n = tk.cnt()[q];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int pos = lane + 64 * e;
         if (pos < KP) {
-          const u64 k = tk.keys[q * CAP + pos];
-          const int64_t o = (gq * nsplit + split) * KP + pos;
-          sl_score[o] = (k == KEY_EMPTY) ? -INFINITY : key_score(k);
-          sl_idx[o] = (k == KEY_EMPTY) ? -1 : key_idx(k);
+          const int64_t o = (gq * nslots + slot) * KP + pos;
+          const bool own = pos < n && tk.sidx()[q * CAP + pos] >= cand_lo;        // seeds of the head pass stay in its slots
+          sl_score[o] = own ? unord_f32(tk.skey()[q * CAP + pos]) : -INFINITY;
+          sl_idx[o] = own ? (int32_t)tk.sidx()[q * CAP + pos] : -1;
         }
       }
+      if (lane == 0) sl_tau[gq * nslots + slot] = tk.tau()[q];
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1, cosine: scores = Qn_cand_tile (A, 32 x d) . Qn_query_block^T (B, d x 32) on fp32 MFMA.
-// DK = d / 8.  Work = (query block, candidate tile) pairs, query-major; every persistent block takes one
-// CONTIGUOUS range of `tpb` tiles (perfect balance, no tail), emitting one shortlist per query-block
-// segment it touches (slot = block - first block touching that query block).
-// BF3: the scores come from bf16 MFMAs on bf16 pieces of both operands (candidates hi + mid + lo = the fp32 significand,
-// queries hi + mid; five piece products).  fp32 MFMA shares the VALU datapath on CDNA (its 157 TFLOP/s
-// is the vector peak, and the shortlist upkeep's VALU work adds to it); the bf16 matrix cores are 16x faster and run
-// beside the VALU, so pass 1 becomes bound by the upkeep alone.  Candidates are split while they are staged
-// (fp32 in HBM/L2: no extra traffic), queries once per segment into registers.
+// stage 0: exact bf16 split of fp32 rows (hi + mid) and the residual maxima for the error bounds
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t n, int d, __bf16* __restrict__ hi,
+                                                         __bf16* __restrict__ mid, uint32_t* __restrict__ mx /*[2] of this operand*/) {
+  // d in {32, 64, 128, 256}: a group of d/4 lanes owns a row (float4 per lane); blocks stride over the rows and keep the
+  // running maxima in registers: ONE pair of atomics per block (one pair per row = 2 x 10^5 same-address atomics = 1.1 ms)
+  __shared__ float red[2][4];
+  const int lpr = d / 4;                                   // lanes per row: 8 .. 64 (a row never straddles a wave)
+  const int rpb = 256 / lpr;                               // rows per block and step
+  const int c4 = threadIdx.x % lpr;
+  float M1 = 0.f, M2 = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + threadIdx.x / lpr; row < n; row += (int64_t)gridDim.x * rpb) {
+    const float4 v = *reinterpret_cast<const float4*>(x + row * d + c4 * 4);
+    const float vf[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 h, m;
+    float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 hh = (__bf16)vf[e];
+      const float a = vf[e] - (float)hh;                   // exact
+      const __bf16 mm = (__bf16)a;
+      const float b = a - (float)mm;                       // exact
+      h[e] = hh; m[e] = mm;
+      r1 += a * a; r2 += b * b;
+    }
+    *reinterpret_cast<bf16x4*>(hi + row * d + c4 * 4) = h;
+    *reinterpret_cast<bf16x4*>(mid + row * d + c4 * 4) = m;
+    for (int o = 1; o < lpr; o <<= 1) { r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); }   // the lanes of a row share its trip count
+    M1 = fmaxf(M1, r1); M2 = fmaxf(M2, r2);
+  }
+  for (int o = 32; o > 0; o >>= 1) { M1 = fmaxf(M1, __shfl_xor(M1, o)); M2 = fmaxf(M2, __shfl_xor(M2, o)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = M1; red[1][threadIdx.x >> 6] = M2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float b = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    atomicMax(&mx[0], ord_f32(sqrtf(a)));
+    atomicMax(&mx[1], ord_f32(sqrtf(b)));
+  }
+}
+
+// admission threshold for the main pass: the best threshold any slot of the head pass reached (each is a lower bound of
+// (k-th best approximate score over ALL candidates) - margin, because it was derived from a subset)
+__global__ void tau_from_slots_kernel(const float* __restrict__ sl_tau, int64_t nq, int nslots, int slot_lo, int slot_hi, float* __restrict__ tau_init) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  float t = -INFINITY;
+  for (int sl = slot_lo; sl < slot_hi; ++sl) t = fmaxf(t, sl_tau[q * nslots + sl]);
+  tau_init[q] = t;
+}
+
+__global__ void init_shortlists_kernel(int32_t* __restrict__ sl_idx, int64_t n_idx, float* __restrict__ sl_tau, int64_t n_tau) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_idx) sl_idx[i] = -1;
+  if (i < n_tau) sl_tau[i] = -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1, cosine.  scores = cand tile (A operand, 32 x d, through LDS) . query block^T (B operand, d x 32, registers) on
+// v_mfma_f32_32x32x16_bf16, so that after the MFMA chain EACH LANE HOLDS 16 SCORES OF ONE QUERY -> one threshold register
+// per lane.  NPROD = 1: cand_hi.query_hi ; 2: + cand_hi.query_mid ; 3: + cand_mid.query_hi (the precise variant).
+// Work = (query block, candidate tile) pairs, query-major; every persistent block takes one CONTIGUOUS range of `tpb`
+// tiles (perfect balance, no tail), emitting one shortlist per query-block segment it touches.  NW waves = NW*32 queries
+// per block, one block per CU; the candidate stage is double-buffered (one barrier per tile) and the loop is software
+// pipelined: the MFMA chain of tile t is issued BEFORE the shortlist upkeep (VALU) of tile t-1, so a wave's matrix work
+// runs beside its own vector work instead of in lock step with its SIMD partner's.
+struct P1Params {
+  const __bf16 *qh, *qm, *ch, *cm;
+  int64_t Nq, Nc;              // queries; candidates OF THIS PASS (rows cand_lo .. cand_lo + Nc - 1 of ch / cm)
+  const int32_t* qlist;        // optional: query rows to process (compact list), else rows 0..Nq-1
+  const int32_t* nq_dev;       // optional: number of entries of qlist (device side); the plan is then made in the kernel
+  int64_t tpb;
+  int nslots;                  // shortlists per query in the workspace (all passes together)
+  float* sl_score; int32_t* sl_idx; float* sl_tau;
+  EpsSrc eps;
+  int k;
+  int64_t cand_lo;             // first candidate row of this pass
+  int slot_base;               // this pass writes slots slot_base ...
+  const float* tau_init;       // optional [Nq]: a valid admission threshold per query to start every segment from
+  int carry_slots;             // with tau_init: slots 0 .. carry_slots-1 (the head pass) seed every segment's buffers
+  int known_tiles;             // candidate tiles the seeds stand for (the head pass's), 0 without seeds
+};
+
 template <int D>
 __device__ __forceinline__ int bf_swz(int row) {          // 16-byte chunk swizzle of the unpadded bf16 piece rows
   constexpr int NCH = D / 8;
@@ -354,223 +366,51 @@ __device__ __forceinline__ int bf_swz(int row) {          // 16-byte chunk swizz
   else if constexpr (NCH == 8) return (row >> 1) & 7;
   else return (row >> 2) & 3;
 }
-__device__ __forceinline__ void bf_split4(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-  const float vf[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 hh = (__bf16)vf[e];
-    const float r1 = vf[e] - (float)hh;                   // exact
-    const __bf16 mm = (__bf16)r1;
-    h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
-  }
-}
 
-template <int DK, int CAPV, int KPV, bool BF3>
-__global__ __launch_bounds__(256) void cosine_pass1_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
-                                                           int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
-                                                           float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
-  typedef WaveTopK<CAPV, KPV> TK;
-  constexpr int D = DK * 8, LD = D + 4;
-  constexpr int NCH = D / 8;                                               // BF3: 16-byte chunks per piece row
-  constexpr size_t STAGE_BYTES = BF3 ? (size_t)CPIECES * CT * D * 2 : sizeof(float) * CT * LD;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* stage = reinterpret_cast<float*>(smem);                           // fp32: [CT][LD]
-  __bf16* stage16 = reinterpret_cast<__bf16*>(smem);                       // BF3 : [3][CT][NCH ^ swizzle][8]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t ntiles = (Nc + CT - 1) / CT;
-  const int64_t nqb = (Nq + QPB - 1) / QPB;
-  const int64_t T = nqb * ntiles;
-  int64_t t = (int64_t)blockIdx.x * tpb;
-  const int64_t t_end = min(T, t + tpb);
-
-  TK tk;
-  tk.carve(smem + STAGE_BYTES + (size_t)wave * TK::BYTES);
-#if defined(KNN_EXP) && KNN_EXP == 9
-  if (lane < 8) tk.dbg[lane] = 0;
-  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  // staging: CT x D floats over 256 threads
-  constexpr int F4_PER_ROW = D / 4;
-  constexpr int NLD = CT * F4_PER_ROW / 256;
-  static_assert(CT * F4_PER_ROW % 256 == 0 && NLD >= 1, "staging split");
-  float4 pre[NLD];
-  auto gload = [&](int64_t ct) {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int f = tid + 256 * j;
-      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      const int64_t gc = ct * CT + r;
-      pre[j] = gc < Nc ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int f = tid + 256 * j;
-      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-      if constexpr (!BF3) {
-        *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) = pre[j];
-      } else {
-        bf16x4 h, m, l;
-        bf_split4(pre[j], h, m, l);
-        const int off = (r * NCH + ((c4 >> 1) ^ bf_swz<D>(r))) * 8 + (c4 & 1) * 4;
-        *reinterpret_cast<bf16x4*>(&stage16[off]) = h;
-        *reinterpret_cast<bf16x4*>(&stage16[CT * D + off]) = m;
-        if constexpr (CPIECES > 2) *reinterpret_cast<bf16x4*>(&stage16[2 * CT * D + off]) = l;
-      }
-    }
-  };
-  const int fr = lane & 31, fh = lane >> 5;
-#if defined(KNN_EXP) && KNN_EXP == 10
-  const unsigned long long cen0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#if defined(KNN_STAGGER)
-  // de-phase the co-resident block pair of a CU (second wave of blocks lands on CUs that already host one):
-  // without it both run their MFMA chains and their bookkeeping at the same time (speed only)
-  if (blockIdx.x >= gridDim.x / 2) { for (int i = 0; i < KNN_STAGGER; ++i) __builtin_amdgcn_s_sleep(32); }
-#endif
-
-  while (t < t_end) {                               // block-uniform: one segment per query block touched
-    const int64_t qb = t / ntiles, ct0 = t % ntiles;
-    const int64_t ct1 = min(ntiles, ct0 + (t_end - t));
-    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
-    const int64_t q0 = qb * QPB + wave * QPW;
-    tk.init(lane);
-    // B fragments (this wave's 32 queries): lane (j = lane&31, h = lane>>5) holds q[j][8kb + 4h + s], s = 0..3
-    float4 bq[BF3 ? 1 : DK];
-    bf16x8 bqp[BF3 ? 2 : 1][BF3 ? D / 16 : 1];   // BF3: lane (j, h) holds the (hi, mid) pieces of q[j][16kb + 8h + e], e = 0..7
-                                                 // (queries keep two pieces -- |q - hi - mid| <= 2^-18 |q| -- to stay within 256 VGPRs)
-    {
-      const int64_t gq = q0 + fr;
-      if constexpr (!BF3) {
-#pragma unroll
-        for (int kb = 0; kb < DK; ++kb)
-          bq[kb] = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 8 + fh * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < D / 16; ++kb)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const float4 v = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 16 + fh * 8 + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bf16x4 h, m, l;
-            bf_split4(v, h, m, l);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { bqp[0][kb][4 * hf + e] = h[e]; bqp[1][kb][4 * hf + e] = m[e]; }
-          }
-      }
-    }
-    float tau = -INFINITY;
-    gload(ct0);
-    for (int64_t ct = ct0; ct < ct1; ++ct) {
-      KSTAMP(s0);
-      sstore();
-      __syncthreads();
-      KSTAMP(s1);
-      if (ct + 1 < ct1) gload(ct + 1);             // next tile flies while this one is scored
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#if defined(KNN_PRIO)
-      __builtin_amdgcn_s_setprio(KNN_PRIO);
-#endif
-      if constexpr (!BF3) {
-        const float* arow = &stage[fr * LD + fh * 4];
-#pragma unroll
-        for (int kb = 0; kb < DK; ++kb) {
-          const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[kb].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[kb].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[kb].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[kb].w, acc, 0, 0, 0);
-        }
-      } else {
-        const int sw = bf_swz<D>(fr);
-#pragma unroll
-        for (int kb = 0; kb < D / 16; ++kb) {
-          const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&stage16[off]);
-          const bf16x8 am = *reinterpret_cast<const bf16x8*>(&stage16[CT * D + off]);
-          // smallest terms first; dropped pieces are in the error bound (2^-18 per operand with two pieces)
-          if constexpr (CPIECES > 2) {
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&stage16[2 * CT * D + off]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], acc, 0, 0, 0);
-          }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], acc, 0, 0, 0);
-        }
-      }
-#if defined(KNN_PRIO)
-      __builtin_amdgcn_s_setprio(0);
-#endif
-      KSTAMP(s2);
-#if !defined(KNN_EXP) || KNN_EXP != 2
-      __syncthreads();                             // the stage buffer may be overwritten from here on
-#endif
-      KSTAMP(s3);
-#if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
-      asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
-#else
-      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
-#endif
-      KSTAMP(s4);
-      KACC(1, s0, s1); KACC(0, s1, s2); KACC(2, s2, s3); KACC(3, s3, s4);
-    }
-    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
-    t += ct1 - ct0;
-  }
-#if defined(KNN_EXP) && KNN_EXP == 10
-  if (tid == 0 && blockIdx.x < 1024) { g_knn_blk[blockIdx.x * 3] = cen0; g_knn_blk[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_knn_blk[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid; }
-#endif
-#if defined(KNN_EXP) && KNN_EXP == 9
-  if (lane == 0) { tk.dbg[6] = __builtin_amdgcn_s_memtime() - kt0; tk.dbg[7] = __builtin_amdgcn_s_memrealtime() - kr0; }
-  if (tid == 0 && blockIdx.x < 1024) { g_knn_blk[blockIdx.x * 3] = kr0; g_knn_blk[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); g_knn_blk[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid; }
-  if (lane < 8) atomicAdd(&g_knn_cnt[lane], tk.dbg[lane]);
-#endif
-}
-
-// pass 1, cosine, bf16 pieces, NW waves per block (NW * 32 queries) and a DOUBLE-BUFFERED candidate stage: one block
-// barrier per tile instead of two, and with NW = 8 (one block per CU) the staging work (global loads, bf16 split, LDS
-// writes) and the candidate traffic per query are half of the 4-wave form.  A wave that is busy with shortlist upkeep
-// holds the others up only when it falls a whole tile behind.
-template <int DK, int CAPV, int KPV, int NW>
-__global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* __restrict__ qq, const float* __restrict__ qc,
-                                                                  int64_t Nq, int64_t Nc, int64_t tpb, int nslots,
-                                                                  float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
+template <int DK, int NPROD, int CAPV, int KPV, int NW>
+__global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p) {
   typedef WaveTopK<CAPV, KPV> TK;
   constexpr int D = DK * 8, NCH = D / 8, NT = 64 * NW, QB = NW * QPW;
-  constexpr int STAGE_ELEMS = CPIECES * CT * D;                             // bf16 elements per buffer
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* stage16 = reinterpret_cast<__bf16*>(smem);                       // [2][CPIECES][CT][NCH ^ swizzle][8]
+  constexpr int CPIECES = NPROD == 3 ? 2 : 1, QPIECES = NPROD >= 2 ? 2 : 1;
+  constexpr int PIECE_ELEMS = CT * D;                                      // bf16 elements of one staged piece
+  constexpr int STAGE_ELEMS = CPIECES * PIECE_ELEMS;
+  static_assert((size_t)2 * STAGE_ELEMS * 2 + (size_t)NW * TK::BYTES <= (size_t)LDS_BYTES, "LDS budget");
+  __bf16* stage16 = reinterpret_cast<__bf16*>(knn_smem);                   // [2][CPIECES][CT][NCH ^ swizzle][8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (Nc + CT - 1) / CT;
-  const int64_t nqb = (Nq + QB - 1) / QB;
+  const int64_t nq = p.nq_dev ? (int64_t)*p.nq_dev : p.Nq;
+  if (nq <= 0) return;
+  const int64_t ntiles = (p.Nc + CT - 1) / CT;
+  const int64_t nqb = (nq + QB - 1) / QB;
   const int64_t T = nqb * ntiles;
+  int64_t tpb = p.tpb;
+  if (p.nq_dev) {                                     // plan made on the device: the row count is not known to the host
+    tpb = (T + gridDim.x - 1) / gridDim.x;
+    const int64_t tpb_min = (ntiles + MAX_SLOTS - 2) / (MAX_SLOTS - 1);
+    if (tpb < tpb_min) tpb = tpb_min;
+  }
   int64_t t = (int64_t)blockIdx.x * tpb;
   const int64_t t_end = min(T, t + tpb);
+  if (t >= t_end) return;
   TK tk;
-  tk.carve(smem + (size_t)2 * STAGE_ELEMS * 2 + (size_t)wave * TK::BYTES);
-#if defined(KNN_EXP) && KNN_EXP == 9
-  if (lane < 8) tk.dbg[lane] = 0;
-  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  tk.carve((unsigned)((size_t)2 * STAGE_ELEMS * 2 + (size_t)wave * TK::BYTES));
+  tk.k = p.k;
+  tk.margin_abs = 2.f * knn_eps(p.eps, NPROD) + 1e-7f;
+  tk.margin_rel = 0.f;
 
-  constexpr int F4_PER_ROW = D / 4, F4_TILE = CT * F4_PER_ROW;
-  constexpr int NLD = (F4_TILE + NT - 1) / NT;
-  float4 pre[NLD];
+  // staging: CT x NCH 16-byte chunks per piece over NT threads
+  constexpr int CH_TILE = CT * NCH;
+  constexpr int NLD = (CH_TILE + NT - 1) / NT;
+  uint4 pre[CPIECES][NLD];
   auto gload = [&](int64_t ct) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + NT * j;
-      const int r = (f / F4_PER_ROW) % CT, c4 = f % F4_PER_ROW;   // (f >= F4_TILE only for tiny D: harmless duplicate)
+      const int r = (f / NCH) % CT, c = f % NCH;      // (f >= CH_TILE only for tiny D: harmless duplicate)
       const int64_t gc = ct * CT + r;
-      pre[j] = gc < Nc ? *reinterpret_cast<const float4*>(qc + gc * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = gc < p.Nc;
+      pre[0][j] = ok ? *reinterpret_cast<const uint4*>(p.ch + (p.cand_lo + gc) * D + c * 8) : make_uint4(0, 0, 0, 0);
+      if constexpr (CPIECES > 1) pre[CPIECES - 1][j] = ok ? *reinterpret_cast<const uint4*>(p.cm + (p.cand_lo + gc) * D + c * 8) : make_uint4(0, 0, 0, 0);
     }
   };
   auto sstore = [&](int buf) {
@@ -578,14 +418,11 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + NT * j;
-      if (F4_TILE % NT == 0 || f < F4_TILE) {
-        const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-        bf16x4 h, m, l;
-        bf_split4(pre[j], h, m, l);
-        const int off = (r * NCH + ((c4 >> 1) ^ bf_swz<D>(r))) * 8 + (c4 & 1) * 4;
-        *reinterpret_cast<bf16x4*>(&st[off]) = h;
-        *reinterpret_cast<bf16x4*>(&st[CT * D + off]) = m;
-        if constexpr (CPIECES > 2) *reinterpret_cast<bf16x4*>(&st[2 * CT * D + off]) = l;
+      if (CH_TILE % NT == 0 || f < CH_TILE) {
+        const int r = f / NCH, c = f % NCH;
+        const int off = (r * NCH + (c ^ bf_swz<D>(r))) * 8;
+        *reinterpret_cast<uint4*>(&st[off]) = pre[0][j];
+        if constexpr (CPIECES > 1) *reinterpret_cast<uint4*>(&st[PIECE_ELEMS + off]) = pre[CPIECES - 1][j];
       }
     }
   };
@@ -595,116 +432,140 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_db_kernel(const float* _
   while (t < t_end) {                               // block-uniform: one segment per query block touched
     const int64_t qb = t / ntiles, ct0 = t % ntiles;
     const int64_t ct1 = min(ntiles, ct0 + (t_end - t));
-    const int slot = (int)(blockIdx.x - (qb * ntiles) / tpb);
+    const int slot = p.slot_base + (int)(blockIdx.x - (qb * ntiles) / tpb);
     const int64_t q0 = qb * QB + wave * QPW;
-    tk.init(lane);
-    bf16x8 bqp[2][D / 16];                          // (hi, mid) pieces of q[j][16kb + 8h + e]
+    // B fragments: lane (j = lane & 31, h = lane >> 5) holds q[j][16 kb + 8 h + e], e = 0..7, per piece
+    bf16x8 bq[QPIECES][D / 16];
     {
       const int64_t gq = q0 + fr;
+      const bool ok = gq < nq;
+      const int64_t qrow = ok ? (p.qlist ? (int64_t)p.qlist[gq] : gq) : 0;
 #pragma unroll
-      for (int kb = 0; kb < D / 16; ++kb)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const float4 v = gq < Nq ? *reinterpret_cast<const float4*>(qq + gq * D + kb * 16 + fh * 8 + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          bf16x4 h, m, l;
-          bf_split4(v, h, m, l);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { bqp[0][kb][4 * hf + e] = h[e]; bqp[1][kb][4 * hf + e] = m[e]; }
+      for (int kb = 0; kb < D / 16; ++kb) {          // rows beyond nq read row 0 and are zeroed (no pointer select: that became a flat load)
+        uint4 v = *reinterpret_cast<const uint4*>(p.qh + qrow * D + kb * 16 + fh * 8);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        bq[0][kb] = __builtin_bit_cast(bf16x8, v);
+        if constexpr (QPIECES > 1) {
+          uint4 m = *reinterpret_cast<const uint4*>(p.qm + qrow * D + kb * 16 + fh * 8);
+          if (!ok) m = make_uint4(0, 0, 0, 0);
+          bq[QPIECES - 1][kb] = __builtin_bit_cast(bf16x8, m);
         }
+      }
     }
     float tau = -INFINITY;
+    if (p.tau_init && q0 + fr < nq) tau = p.tau_init[q0 + fr];
+    tk.init(lane, tau);
+    if (p.tau_init) {
+      // Seed the buffers with the head pass's entries above the threshold: the segment then CONTINUES the head's stream
+      // (its k-th best can only rise from there) instead of re-learning the threshold from its own candidates alone.
+      // Seeds are not emitted again (emit_shortlists skips candidates below cand_lo); dropping seeds is always safe.
+      for (int qq = 0; qq < QPW; ++qq) {
+        const int64_t gq = q0 + qq;
+        if (gq >= nq) break;
+        const float t0 = p.tau_init[gq];
+        int have = 0;
+        const int ne = p.carry_slots * KPV;
+        for (int e0 = 0; e0 < ne && have < CAPV; e0 += 64) {
+          const int e = e0 + lane;
+          const int64_t o = gq * p.nslots * KPV + e;            // head slots are the first ones of the query's row
+          const int32_t c = e < ne ? p.sl_idx[o] : -1;
+          const float sc = e < ne ? p.sl_score[o] : -INFINITY;
+          const bool kp = c >= 0 && sc > t0;
+          const unsigned long long b = __ballot(kp);
+          const int pos = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+          if (kp && pos < CAPV) { tk.skey()[qq * CAPV + pos] = ord_f32(sc); tk.sidx()[qq * CAPV + pos] = (uint32_t)c; }
+          have += __popcll(b);
+        }
+        if (lane == 0) tk.cnt()[qq] = have < CAPV ? have : CAPV;
+      }
+    }
     __syncthreads();                                // the previous segment's last tile has been read by every wave
     gload(ct0);
     sstore(0);
     if (ct0 + 1 < ct1) gload(ct0 + 1);
-    // score one tile from stage[cur] on the matrix cores
+    __syncthreads();
     auto score = [&](int cur) {
-      // two independent accumulator chains (even / odd k blocks): a single dependent chain of 32x32x16 bf16 MFMAs issues
-      // one instruction per 64 cycles, half the matrix pipe's rate (tools/micro/mfma_valu_overlap.hip)
-      f32x16 acc, acc2;
+      // ONE accumulation chain: back-to-back 32x32x16 bf16 MFMAs on one accumulator issue at the pipe's full rate
+      // (MI355X_MICROARCH.md, cycle constants), so no second chain and no merge adds
+      f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const __bf16* st = stage16 + cur * STAGE_ELEMS;
+      bf16x8 ahv[D / 16];                             // every A fragment of the tile is requested before the first MFMA waits
+#pragma unroll
+      for (int kb = 0; kb < D / 16; ++kb) ahv[kb] = *reinterpret_cast<const bf16x8*>(&st[(fr * NCH + ((2 * kb + fh) ^ sw)) * 8]);
 #pragma unroll
       for (int kb = 0; kb < D / 16; ++kb) {
         const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&st[off]);
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(&st[CT * D + off]);
-        f32x16& a = (kb & 1) ? acc2 : acc;
-        if constexpr (CPIECES > 2) {
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&st[2 * CT * D + off]);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bqp[0][kb], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[1][kb], a, 0, 0, 0);
+        const bf16x8 ah = ahv[kb];
+        f32x16& a = acc;
+        // smallest terms first
+        if constexpr (NPROD == 3) {
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(&st[PIECE_ELEMS + off]);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[0][kb], a, 0, 0, 0);
         }
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bqp[0][kb], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[1][kb], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bqp[0][kb], a, 0, 0, 0);
+        if constexpr (NPROD >= 2) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[QPIECES - 1][kb], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[0][kb], a, 0, 0, 0);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
       return acc;
     };
-    auto offer = [&](const f32x16& acc, int64_t ct) {
-#if defined(KNN_EXP) && (KNN_EXP == 1 || KNN_EXP == 3)
-      asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[15]));   // timing experiment: scores stay live, no shortlist
-#else
-      offer_tile(tk, acc, (int)(ct * CT), Nc, lane, tau, ((ct - ct0) % DRAIN_EVERY) == DRAIN_EVERY - 1);
-#endif
-    };
-    // Cycle stamps (-DKNN_EXP=9, tools/knn_exp.py) per wave and tile: scoring 1530 (two waves share a SIMD's matrix pipe:
-    // 2 x 768), staging 660, barrier wait 1350, shortlist upkeep 1670 (queueing 980, drains 690 of which compaction 520).
-    // Negative results: the skewed schedule below and parking single passes in per-lane registers until the next drain
-    // (12.5 ms).
-    // Tried and removed: a skewed schedule in which the second wave of every SIMD (waves w and w + NW/2
-    // share one: tools/micro/wave_simd_map.hip) does the upkeep of tile t-1 before it scores tile t -- 13.2 vs 11.8 ms;
-    // skewing only the staging was equally flat.
-    {
+    f32x16 accP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[r] = -INFINITY;
     int cur = 0;
-    for (int64_t ct = ct0; ct < ct1; ++ct, cur ^= 1) {
-      KSTAMP(s0);
-      __syncthreads();                              // stage[cur] complete; nobody reads stage[cur^1] (tile ct-1) any more
-      KSTAMP(s1);
-      if (ct + 1 < ct1) sstore(cur ^ 1);            // tile ct+1: registers -> the free buffer
-      if (ct + 2 < ct1) gload(ct + 2);              // tile ct+2 flies while this one is scored
-      KSTAMP(s2);
-      const f32x16 acc = score(cur);
-#if defined(KNN_EXP) && KNN_EXP == 9
-      asm volatile("s_nop 0" ::"v"(acc[15]));
-#endif
-      KSTAMP(s3);
-      offer(acc, ct);
-      KSTAMP(s4);
-      KACC(2, s0, s1); KACC(1, s1, s2); KACC(0, s2, s3); KACC(3, s3, s4);
+    const int nt = (int)(ct1 - ct0);                    // tiles of this segment (32-bit loop arithmetic)
+    // SCHEDULED compactions.  A buffer would otherwise be compacted whenever it happens to fill: ~14 times per query at
+    // unpredictable tiles, and every such call (~3000 cycles) holds all eight waves at the tile barrier (measured: 1860
+    // of 4400 cycles per wave and tile were barrier wait).  The admission rate of a stream at position g is ~ K / g, so
+    // compacting EVERY buffer when g crosses 2, 3, 5, 8, 13, ... (x 1.6) keeps the expected arrivals between two
+    // compactions at K ln 1.6 ~ 16 < the buffers' slack: the waves compact at the same tiles and stay in step.
+    int next_c = p.known_tiles > 0 ? p.known_tiles + (p.known_tiles * KNN_SCHED_NUM >> 3) : 2;
+    for (int i = 0; i < nt; ++i, cur ^= 1) {
+      const f32x16 accN = score(cur);                   // tile ct0+i: LDS reads + MFMA chain issued first ...
+      if (i + 1 < nt) sstore(cur ^ 1);                  // tile i+1: registers -> the buffer tile i-1 was read from
+      if (i + 2 < nt) gload(ct0 + i + 2);               // tile i+2 flies
+      if (i > 0) {                                      // ... the upkeep of tile i-1 runs beside them
+        offer_tile(tk, accP, (int)(ct0 + i - 1) * CT, p.Nc, (int)p.cand_lo, lane, tau);
+        if (p.known_tiles + i >= next_c) {
+          // only the buffers that could fill before the next scheduled compaction (the others keep their slack)
+          const unsigned long long fullish = __ballot(lane < QPW && tk.cnt()[lane & 31] > CAPV - KNN_SCHED_FREE);
+          compact_rows(tk, (unsigned int)fullish, lane);
+          tau = tk.tau()[lane & 31];
+          next_c += (next_c * KNN_SCHED_NUM >> 3) > 0 ? (next_c * KNN_SCHED_NUM >> 3) : 1;
+        }
+      }
+      __syncthreads();                                  // stage[cur^1] complete; nobody reads stage[cur] any more
+      accP = accN;
     }
-    }
-    emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, slot, nslots);
+    offer_tile(tk, accP, (int)(ct1 - 1) * CT, p.Nc, (int)p.cand_lo, lane, tau);
+    emit_shortlists(tk, lane, q0, nq, p.sl_score, p.sl_idx, p.sl_tau, slot, p.nslots, (uint32_t)p.cand_lo);
     t += ct1 - ct0;
   }
-#if defined(KNN_EXP) && KNN_EXP == 9
-  if (lane == 0) { tk.dbg[6] = __builtin_amdgcn_s_memtime() - kt0; tk.dbg[7] = __builtin_amdgcn_s_memrealtime() - kr0; }
-  if (lane < 8) atomicAdd(&g_knn_cnt[lane], tk.dbg[lane]);
-#endif
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // pass 1, mlp (Similar_v2 'mlp' in separable eval form, H = 128): fp32 VALU scoring, same shortlist.
 constexpr int MLP_H = 128;
-template <int EPL>
+constexpr int MLP_WAVES = 4;
+template <int CAPV, int KPV>
 __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           const float* __restrict__ w2, float b2, int64_t Nq, int64_t Nc,
-                                                           float* __restrict__ sl_score, int32_t* __restrict__ sl_idx) {
-  typedef WaveTopK<64 * EPL, 32 * EPL> TK;
+                                                           const float* __restrict__ w2, float b2, int64_t Nq, int64_t Nc, int k,
+                                                           float err_abs, float err_rel,
+                                                           float* __restrict__ sl_score, int32_t* __restrict__ sl_idx,
+                                                           float* __restrict__ sl_tau) {
+  typedef WaveTopK<CAPV, KPV> TK;
   constexpr int H = MLP_H, LD = H + 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* stage = reinterpret_cast<float*>(smem);                                    // [CT][LD]
+  float* stage = reinterpret_cast<float*>(knn_smem);                                // [CT][LD]
   float* coefs = stage + CT * LD;                                                   // scale|shift|w2 [3][H]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t q0 = (int64_t)blockIdx.x * QPB + wave * QPW;
+  const int64_t q0 = (int64_t)blockIdx.x * (MLP_WAVES * QPW) + wave * QPW;
   TK tk;
-  tk.carve(reinterpret_cast<unsigned char*>(coefs + 3 * H) + (size_t)wave * TK::BYTES);
-  tk.init(lane);
+  tk.carve((unsigned)(sizeof(float) * (CT * LD + 3 * H) + (size_t)wave * TK::BYTES));
+  tk.k = k;
+  tk.margin_abs = 2.f * err_abs + 1e-7f;
+  tk.margin_rel = 2.f * err_rel;
+  tk.init(lane, -INFINITY);
   for (int t = tid; t < H; t += 256) { coefs[t] = scale[t]; coefs[H + t] = shift[t]; coefs[2 * H + t] = w2[t]; }
   float4 bqv[H / 4];                 // this lane's query row B[q][:], statically indexed (registers)
   {
@@ -743,9 +604,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
         acc[r] = fmaf(w.w, fmaxf(fmaf(sc.w, a.w + bb.w, sh.w), 0.f), acc[r]);
       }
     }
-    offer_tile(tk, acc, (int)cb, Nc, lane, tau, true);
+    offer_tile(tk, acc, (int)cb, Nc, 0, lane, tau);
   }
-  emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, 0, 1);
+  emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, sl_tau, 0, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -786,65 +647,82 @@ struct MlpCanon {
 
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf(-x)); }
 
-// pass 2: one wave per query.  L = nsplit*KP shortlist entries.
+// pass 2: one wave per query.  L = nslots*KP shortlist entries + nslots thresholds.
+//   alast = max over the slots' thresholds = the best approximate score any excluded candidate can have;
+//   survivors = listed candidates with approximate score > alast (a candidate at or below it is dominated by the k
+//   listed candidates of the slot that set alast, whose approximate scores exceed it by the margin 2 eps);
+//   exact re-score + rank of the survivors; proof  kth_exact > alast + bound.
+struct RefineParams {
+  int64_t Nq; const int32_t* qlist; const int32_t* nq_dev;
+  int k, L, KP, nslots;
+  const float* sl_score; const int32_t* sl_idx; const float* sl_tau;
+  EpsSrc eps; int nprod;                 // nprod > 0: bound from the residual maxima; else err_abs + err_rel |alast|
+  double err_abs, err_rel;
+  int apply_sigmoid;
+  int64_t* idx_out; float* val_out;
+  int32_t* fail_list; int32_t* fail_count;
+};
 template <class Canon>
-__global__ __launch_bounds__(256) void refine_kernel(Canon canon, int64_t Nq, int k, int L, int KP, int nsplit,
-                                                     const float* __restrict__ sl_score, const int32_t* __restrict__ sl_idx,
-                                                     double err_abs, double err_rel, int apply_sigmoid,
-                                                     int64_t* __restrict__ idx_out, float* __restrict__ val_out,
-                                                     int32_t* __restrict__ fb_list, int32_t* __restrict__ fb_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ __launch_bounds__(256) void refine_kernel(Canon canon, const RefineParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* es = reinterpret_cast<double*>(smem) + (size_t)wave * L;                        // exact scores
-  int32_t* ei = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(smem) + (size_t)4 * L) + (size_t)wave * L;
-  for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < Nq; q += (int64_t)gridDim.x * 4) {
-    float alast = -INFINITY;   // best approximate score any excluded candidate can have
-    for (int e = lane; e < L; e += 64) {
-      const int32_t c = sl_idx[q * L + e];
-      ei[e] = c;
-      es[e] = c >= 0 ? canon(q, c) : -INFINITY;
-      if ((e % KP) == KP - 1 && c >= 0) alast = fmaxf(alast, sl_score[q * L + e]);   // full split
-    }
+  const int L = p.L;
+  double* es = reinterpret_cast<double*>(knn_smem) + (size_t)wave * L;                    // exact scores of the survivors
+  int32_t* ei = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(knn_smem) + (size_t)4 * L) + (size_t)wave * L;
+  const int64_t nq = p.nq_dev ? (int64_t)*p.nq_dev : p.Nq;
+  const double eps = p.nprod > 0 ? (double)knn_eps(p.eps, p.nprod) : 0.0;
+  for (int64_t qi = (int64_t)blockIdx.x * 4 + wave; qi < nq; qi += (int64_t)gridDim.x * 4) {
+    const int64_t q = p.qlist ? (int64_t)p.qlist[qi] : qi;
+    float alast = -INFINITY;
+    for (int s = lane; s < p.nslots; s += 64) alast = fmaxf(alast, p.sl_tau[qi * p.nslots + s]);
     alast = bgnn::group_max<64>(alast);
+    int ns = 0;
+    for (int e0 = 0; e0 < L; e0 += 64) {
+      const int e = e0 + lane;
+      const int32_t c = e < L ? p.sl_idx[qi * L + e] : -1;
+      const bool surv = c >= 0 && p.sl_score[qi * L + e] > alast;
+      const unsigned long long b = __ballot(surv);
+      if (surv) {
+        const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        ei[pos] = c;
+        es[pos] = canon(q, c);
+      }
+      ns += __popcll(b);
+    }
     __builtin_amdgcn_s_waitcnt(0);   // LDS writes above complete before the cross-lane reads below
     __builtin_amdgcn_wave_barrier();
     double kth = -INFINITY;
-    for (int e = lane; e < L; e += 64) {
+    for (int e = lane; e < ns; e += 64) {
       const double s = es[e];
       const int32_t c = ei[e];
       int rank = 0;
-      if (c >= 0) {
-        for (int j = 0; j < L; ++j) {
-          const double sj = es[j];
-          const int32_t cj = ei[j];
-          rank += (cj >= 0) && (sj > s || (sj == s && cj < c));
-        }
-        if (rank < k) {
-          idx_out[q * k + rank] = c;
-          val_out[q * k + rank] = apply_sigmoid ? sigmoid_f32((float)s) : (float)s;
-        }
-        if (rank == k - 1) kth = s;
+      for (int j = 0; j < ns; ++j) {
+        const double sj = es[j];
+        const int32_t cj = ei[j];
+        rank += (sj > s || (sj == s && cj < c));
       }
+      if (rank < p.k) {
+        p.idx_out[q * p.k + rank] = c;
+        p.val_out[q * p.k + rank] = p.apply_sigmoid ? sigmoid_f32((float)s) : (float)s;
+      }
+      if (rank == p.k - 1) kth = s;
     }
-    // broadcast kth (exactly one lane holds it when >= k valid entries exist)
-    double kmax = kth;
+    double kmax = kth;                 // exactly one lane holds it when >= k survivors exist
     for (int o = 32; o > 0; o >>= 1) {
       const double other = __shfl_xor(kmax, o);
       kmax = other > kmax ? other : kmax;
     }
-    const bool have = kmax > -INFINITY;
-    // proof: every excluded candidate has exact score <= alast + bound < kth
-    const double bound = err_abs + err_rel * fabs((double)alast);
-    const bool proven = (alast == -INFINITY) || (have && kmax > (double)alast + bound);
+    const bool have = ns >= p.k;
+    const double bound = p.nprod > 0 ? eps : p.err_abs + p.err_rel * fabs((double)alast);
+    const bool proven = have && ((alast == -INFINITY) || kmax > (double)alast + bound);
     if (!proven && lane == 0) {
-      const int slot = atomicAdd(fb_count, 1);
-      fb_list[slot] = (int32_t)q;
+      const int slot = atomicAdd(p.fail_count, 1);
+      p.fail_list[slot] = (int32_t)q;
     }
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// pass 3: exhaustive canonical re-do of queued rows.  One block per queued row (grid-strided).
+// last stage: exhaustive canonical re-do of queued rows.  One block per queued row (grid-strided).
 template <class Canon>
 __global__ __launch_bounds__(256) void fallback_kernel(Canon canon, int64_t Nc, int k, int apply_sigmoid,
                                                        const int32_t* __restrict__ fb_list, const int32_t* __restrict__ fb_count,
@@ -936,26 +814,21 @@ __global__ void normalize_rows_wide_kernel(const float* __restrict__ q, int64_t 
   for (int c = 0; c < d; ++c) out[i * d + c] = __fdiv_rn(r[c], nr);
 }
 
-__global__ void copy_count_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) { *dst = *src; }
+__global__ void copy_counts_kernel(const int32_t* __restrict__ exhaustive, const int32_t* __restrict__ precise, int32_t* __restrict__ dst) {
+  dst[0] = *exhaustive;
+  if (precise) dst[1] = *precise;
+}
 
-struct TopkWs {
-  float* sl_score; int32_t* sl_idx; int32_t* fb_list; int32_t* fb_count; double* scratch;
-  int fb_blocks;
-};
-constexpr int FB_BLOCKS = 64;
-#ifndef KNN_KP_SMALL
-#define KNN_KP_SMALL 24      // live shortlist size for k <= KNN_KP_SMALL - 4
-#define KNN_CAP_SMALL 48
-#endif
-static int pick_kp(int k) { return k <= KNN_KP_SMALL - 4 ? KNN_KP_SMALL : (k <= 24 ? 32 : 64); }
-constexpr int MAX_SLOTS = 8;
+// ------------------------------------------------------------------------------------------------
+// host side: geometry and workspace
+struct Geom { int cap, kp; };                       // shortlist geometry by k
+static Geom geom_fast(int k) { return k <= 20 ? Geom{64, 48} : Geom{128, 112}; }
+static Geom geom_precise(int k) { return k <= 20 ? Geom{64, 32} : Geom{128, 96}; }
+static Geom geom_mlp(int k) { return k <= 24 ? Geom{64, 40} : Geom{128, 112}; }
+static int max_kp(int k) { return geom_fast(k).kp; }
 
-// geometry of pass 1 for a problem: persistent blocks, tiles per block, shortlist slots per query
-struct Pass1Plan {
-  int64_t nblocks, tpb;
-  int nslots;
-};
-static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int qpb = QPB) {
+struct Pass1Plan { int64_t nblocks, tpb; int nslots; };
+static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int qpb) {
   const int64_t ntiles = (Nc + CT - 1) / CT, nqb = (Nq + qpb - 1) / qpb, T = ntiles * nqb;
   Pass1Plan pl;
   pl.nblocks = T < resident_blocks ? T : resident_blocks;
@@ -965,112 +838,120 @@ static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int
   if (pl.tpb < tpb_min) pl.tpb = tpb_min;
   pl.nblocks = (T + pl.tpb - 1) / pl.tpb;
   pl.nslots = (int)((ntiles + pl.tpb - 1) / pl.tpb) + 1;     // blocks that can touch one query block
+  if (pl.nslots > MAX_SLOTS) pl.nslots = MAX_SLOTS;
   return pl;
 }
-// upper bound used for workspace sizing when the occupancy query is not yet known: 2 blocks per CU, 256 CUs
-constexpr int64_t RESIDENT_MAX = 1024;
-static int worst_slots(int64_t Nq, int64_t Nc) {
-  int m = 2;
-  for (int64_t rb = 1; rb <= RESIDENT_MAX; rb *= 2) {
-    const int s1 = plan_pass1(Nq, Nc, rb).nslots, s2 = plan_pass1(Nq, Nc, rb, 2 * QPB).nslots;
-    if (s1 > m) m = s1;
-    if (s2 > m) m = s2;
-  }
-  return m;
-}
 
-static size_t topk_ws_bytes(int64_t Nq, int64_t Nc, int k) {
-  const size_t L = (size_t)worst_slots(Nq, Nc) * pick_kp(k);
-  size_t b = 0;
-  b += bgnn_align_up(sizeof(float) * Nq * L, 256);
-  b += bgnn_align_up(sizeof(int32_t) * Nq * L, 256);
-  b += bgnn_align_up(sizeof(int32_t) * (Nq + 1), 256);
-  b += 256;
-  b += bgnn_align_up(sizeof(double) * FB_BLOCKS * Nc, 256);
-  return b + 256;
-}
-static TopkWs topk_carve(void* ws, int64_t Nq, int64_t Nc, int k) {
-  const size_t L = (size_t)worst_slots(Nq, Nc) * pick_kp(k);
+struct TopkWs {
+  float* sl_score; int32_t* sl_idx; float* sl_tau;      // stage 1 shortlists  [Nq][<= 2 MAX_SLOTS][KP]
+  float* tau_init;                                      // [Nq] thresholds handed from the head pass to the main pass
+  float* sl2_score; int32_t* sl2_idx; float* sl2_tau;   // stage 3 (precise) shortlists, indexed by position in fail1
+  int32_t* fail1; int32_t* fail2; int32_t* counts;      // counts[0] = precise rows, counts[1] = exhaustive rows
+  uint32_t* mx;                                         // residual maxima [4]
+  __bf16 *qh, *qm, *ch, *cm;
+  double* scratch;
+  int fb_blocks;
+};
+constexpr int FB_BLOCKS = 64;
+static size_t topk_ws_layout(int64_t Nq, int64_t Nc, int k, int d, TopkWs* w, void* ws) {
   char* p = (char*)ws;
-  auto take = [&](size_t bytes) { char* q = p; p += bgnn_align_up(bytes, 256); return q; };
-  TopkWs w;
-  w.sl_score = (float*)take(sizeof(float) * Nq * L);
-  w.sl_idx = (int32_t*)take(sizeof(int32_t) * Nq * L);
-  w.fb_list = (int32_t*)take(sizeof(int32_t) * (Nq + 1));
-  w.fb_count = (int32_t*)take(256);
-  w.scratch = (double*)take(sizeof(double) * FB_BLOCKS * Nc);
-  w.fb_blocks = FB_BLOCKS;
-  return w;
+  size_t total = 0;
+  auto take = [&](size_t bytes) { char* q = p ? p + total : nullptr; total += bgnn_align_up(bytes, 256); return q; };
+  const size_t L1 = (size_t)2 * MAX_SLOTS * max_kp(k), L2 = (size_t)MAX_SLOTS * geom_precise(k).kp;      // head + main pass slots
+  char* a0 = take(sizeof(float) * Nq * L1);
+  char* a1 = take(sizeof(int32_t) * Nq * L1);
+  char* a2 = take(sizeof(float) * Nq * 2 * MAX_SLOTS);
+  char* a3 = take(sizeof(float) * Nq);
+  char* b0 = take(sizeof(float) * Nq * L2);
+  char* b1 = take(sizeof(int32_t) * Nq * L2);
+  char* b2 = take(sizeof(float) * Nq * MAX_SLOTS);
+  char* f1 = take(sizeof(int32_t) * (Nq + 1));
+  char* f2 = take(sizeof(int32_t) * (Nq + 1));
+  char* cn = take(256);
+  char* mx = take(256);
+  char* qh = take(sizeof(__bf16) * Nq * d);
+  char* qm = take(sizeof(__bf16) * Nq * d);
+  char* ch = take(sizeof(__bf16) * Nc * d);
+  char* cm = take(sizeof(__bf16) * Nc * d);
+  char* sc = take(sizeof(double) * FB_BLOCKS * Nc);
+  if (w) {
+    w->sl_score = (float*)a0; w->sl_idx = (int32_t*)a1; w->sl_tau = (float*)a2; w->tau_init = (float*)a3;
+    w->sl2_score = (float*)b0; w->sl2_idx = (int32_t*)b1; w->sl2_tau = (float*)b2;
+    w->fail1 = (int32_t*)f1; w->fail2 = (int32_t*)f2; w->counts = (int32_t*)cn; w->mx = (uint32_t*)mx;
+    w->qh = (__bf16*)qh; w->qm = (__bf16*)qm; w->ch = (__bf16*)ch; w->cm = (__bf16*)cm;
+    w->scratch = (double*)sc; w->fb_blocks = FB_BLOCKS;
+  }
+  return total + 256;
 }
 
-template <class Canon>
-static int run_refine(const Canon& canon, int64_t Nq, int64_t Nc, int k, int KP, int nsplit, const TopkWs& w,
-                      double err_abs, double err_rel, int apply_sigmoid, int64_t* idx_out, float* val_out,
-                      int32_t* n_fallback_opt, hipStream_t st) {
-  hipError_t e;
-  if ((e = hipMemsetAsync(w.fb_count, 0, sizeof(int32_t), st)) != hipSuccess) return (int)e;
-  const int L = KP * nsplit;
-  int64_t grid = (Nq + 3) / 4;
-  if (grid > 2048) grid = 2048;
-  const size_t sh = (size_t)4 * L * (sizeof(double) + sizeof(int32_t));
-  hipLaunchKernelGGL((refine_kernel<Canon>), dim3((unsigned)grid), dim3(256), sh, st, canon, Nq, k, L, KP, nsplit,
-                     w.sl_score, w.sl_idx, err_abs, err_rel, apply_sigmoid, idx_out, val_out, w.fb_list, w.fb_count);
+static int device_cus() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  return prop.multiProcessorCount;
+}
+
+// waves per block of a pass-1 instantiation: the most that fit the 160 KB of LDS next to the double-buffered stage
+template <int DK, int NPROD, int CAPV>
+constexpr int pass1_waves() {
+  constexpr size_t stage = (size_t)2 * (NPROD == 3 ? 2 : 1) * CT * DK * 8 * 2;
+  constexpr size_t per_wave = sizeof(u64) * QPW * CAPV + 2 * 4 * QPW;
+  return (stage + 8 * per_wave <= (size_t)LDS_BYTES) ? 8 : (stage + 4 * per_wave <= (size_t)LDS_BYTES) ? 4 : (stage + 2 * per_wave <= (size_t)LDS_BYTES) ? 2 : 1;
+}
+
+template <int DK, int NPROD, int CAPV, int KPV>
+static int launch_pass1(P1Params p, const Pass1Plan* plan /* nullptr: the kernel plans from the device-side row count */, hipStream_t st) {
+  constexpr int NW = pass1_waves<DK, NPROD, CAPV>();
+  constexpr size_t sh = (size_t)2 * (NPROD == 3 ? 2 : 1) * CT * DK * 8 * 2 + (size_t)NW * WaveTopK<CAPV, KPV>::BYTES;
+  auto kern = cosine_pass1_kernel<DK, NPROD, CAPV, KPV, NW>;
+  static int attr_done[BGNN_MAX_DEVICES];
+  hipError_t e = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)sh, attr_done);
+  if (e != hipSuccess) return (int)e;
+  const int cus = device_cus();
+  if (cus < 1) return (int)hipErrorInvalidDevice;
+  p.tpb = plan ? plan->tpb : 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(plan ? plan->nblocks : cus)), dim3(64 * NW), sh, st, p);
   BGNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((fallback_kernel<Canon>), dim3(w.fb_blocks), dim3(256), 0, st, canon, Nc, k, apply_sigmoid,
-                     w.fb_list, w.fb_count, w.scratch, idx_out, val_out);
-  BGNN_LAUNCH_CHECK();
-  if (n_fallback_opt) {
-    hipLaunchKernelGGL(copy_count_kernel, dim3(1), dim3(1), 0, st, w.fb_count, n_fallback_opt);
-    BGNN_LAUNCH_CHECK();
-  }
   return 0;
 }
 
-template <int DK, int CAPV, int KPV, bool BF3>
-static int launch_cosine_pass1(const float* qq, const float* qc, int64_t Nq, int64_t Nc, const TopkWs& w, int* nslots_out,
-                               hipStream_t st) {
-  constexpr int D = DK * 8, LD = D + 4;
-  hipError_t e;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-  static const int db_nw = [] { const char* e = getenv("BGNN_KNN_DB"); return e ? atoi(e) : 8; }();   // 0 = two-barrier 4-wave form
-  if constexpr (BF3) {
-    constexpr size_t sh8 = (size_t)2 * CPIECES * CT * D * 2 + 8 * WaveTopK<CAPV, KPV>::BYTES;
-    if (db_nw == 8 && sh8 <= 160 * 1024) {
-      auto k8 = cosine_pass1_db_kernel<DK, CAPV, KPV, 8>;
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh8);
-      if (attr != hipSuccess) return (int)attr;
-      const Pass1Plan pl = plan_pass1(Nq, Nc, prop.multiProcessorCount, 2 * QPB);     // one 8-wave block per CU
-      *nslots_out = pl.nslots;
-      if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(k8, dim3((unsigned)pl.nblocks), dim3(512), sh8, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
-      BGNN_LAUNCH_CHECK();
-      return 0;
-    }
+// dispatch over (embedding width, product set, shortlist geometry); `qpb_out` != nullptr only asks for the query rows per block
+template <int DK>
+static int pass1_dk(int nprod, int k, const P1Params& p, const Pass1Plan* plan, int* qpb_out, hipStream_t st) {
+#define BGNN_P1(NP, CAPV, KPV)                                                                         \
+  do {                                                                                                 \
+    if (qpb_out) { *qpb_out = pass1_waves<DK, NP, CAPV>() * QPW; return 0; }                           \
+    return launch_pass1<DK, NP, CAPV, KPV>(p, plan, st);                                               \
+  } while (0)
+  if (nprod == 3) { if (geom_precise(k).cap == 64) BGNN_P1(3, 64, 32); else BGNN_P1(3, 128, 96); }
+  if (nprod == 2) { if (geom_fast(k).cap == 64) BGNN_P1(2, 64, 48); else BGNN_P1(2, 128, 112); }
+  if (geom_fast(k).cap == 64) BGNN_P1(1, 64, 48); else BGNN_P1(1, 128, 112);
+#undef BGNN_P1
+}
+static int pass1_any(int d, int nprod, int k, const P1Params& p, const Pass1Plan* plan, int* qpb_out, hipStream_t st) {
+  switch (d) {
+    case 32: return pass1_dk<4>(nprod, k, p, plan, qpb_out, st);
+    case 64: return pass1_dk<8>(nprod, k, p, plan, qpb_out, st);
+    case 128: return pass1_dk<16>(nprod, k, p, plan, qpb_out, st);
+    default: return pass1_dk<32>(nprod, k, p, plan, qpb_out, st);
   }
-  const size_t sh = (BF3 ? (size_t)CPIECES * CT * D * 2 : sizeof(float) * CT * LD) + WAVES * WaveTopK<CAPV, KPV>::BYTES;
-  auto kern = cosine_pass1_kernel<DK, CAPV, KPV, BF3>;
-  // immutable per (instantiation, device): how many blocks are co-resident.  The occupancy API prices LDS
-  // against 64 KB per CU on ROCm 7.2 and answers 1 here; gfx950 has 160 KB per CU, and this kernel's
-  // <= 256 VGPRs allow two waves per SIMD, so the residency is computed from those two budgets.
-  static const int resident = [&] {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return -1;
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) != hipSuccess) return -1;
-    int per_cu = (int)((160 * 1024) / sh);          // the kernel has no static LDS
-    const int by_regs = fa.numRegs > 0 ? 512 / ((fa.numRegs + 7) / 8 * 8) : 1;     // waves per SIMD = blocks per CU (4 waves)
-    if (per_cu > by_regs) per_cu = by_regs;
-    if (per_cu > 2) per_cu = 2;
-    if (per_cu < 1) per_cu = 1;
-    const int r = per_cu * prop.multiProcessorCount;
-    return r > (int)RESIDENT_MAX ? (int)RESIDENT_MAX : r;
-  }();
-  if (resident < 1) return (int)hipErrorInvalidValue;
-  const Pass1Plan pl = plan_pass1(Nq, Nc, resident);
-  *nslots_out = pl.nslots;
-  if ((e = hipMemsetAsync(w.sl_idx, 0xFF, sizeof(int32_t) * Nq * pl.nslots * KPV, st)) != hipSuccess) return (int)e;   // every slot starts empty (-1)
-  hipLaunchKernelGGL(kern, dim3((unsigned)pl.nblocks), dim3(256), sh, st, qq, qc, Nq, Nc, pl.tpb, pl.nslots, w.sl_score, w.sl_idx);
+}
+
+template <class Canon>
+static int launch_refine(const Canon& canon, const RefineParams& rp, hipStream_t st) {
+  int64_t grid = (rp.Nq + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  const size_t sh = (size_t)4 * rp.L * (sizeof(double) + sizeof(int32_t));
+  hipLaunchKernelGGL((refine_kernel<Canon>), dim3((unsigned)grid), dim3(256), sh, st, canon, rp);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int init_shortlists(int32_t* sl_idx, int64_t n_idx, float* sl_tau, int64_t n_tau, hipStream_t st) {
+  const int64_t n = n_idx > n_tau ? n_idx : n_tau;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(init_shortlists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sl_idx, n_idx, sl_tau, n_tau);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
@@ -1094,7 +975,7 @@ extern "C" int bgnn_l2_normalize_rows_f32(const float* q, int64_t n, int32_t d, 
 }
 
 extern "C" size_t bgnn_topk_workspace_bytes(int64_t Nq, int64_t Nc, int32_t k) {
-  return topk_ws_bytes(Nq < 1 ? 1 : Nq, Nc < 1 ? 1 : Nc, k);
+  return topk_ws_layout(Nq < 1 ? 1 : Nq, Nc < 1 ? 1 : Nc, k, 256, nullptr, nullptr);      // embedding width <= 256
 }
 
 extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand, int64_t Nq, int64_t Nc,
@@ -1104,35 +985,80 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   if (Nq < 0 || Nc <= 0 || Nc >= (int64_t)1 << 31 || d <= 0) return BGNN_E_SHAPE;
   if (d != 32 && d != 64 && d != 128 && d != 256) return BGNN_E_SHAPE;   // callers zero-pad d
   if (k <= 0 || k > 56 || k > Nc) return BGNN_E_RANGE;
-  if (d == 256 && k > 24) return BGNN_E_SHAPE;   // LDS budget (shortlists 128 KB + staging)
   if (!bgnn_aligned16(qn_query) || !bgnn_aligned16(qn_cand)) return BGNN_E_ALIGN;
-  if (ws_bytes < topk_ws_bytes(Nq, Nc, k)) return BGNN_E_WORKSPACE;
+  if (ws_bytes < topk_ws_layout(Nq < 1 ? 1 : Nq, Nc, k, d, nullptr, nullptr)) return BGNN_E_WORKSPACE;
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  TopkWs w = topk_carve(ws, Nq, Nc, k);
-  const int KP = pick_kp(k);
-  int nsplit = 1;
-  int rc;
-  static const bool bf3 = [] { const char* e = getenv("BGNN_KNN_BF3"); return !e || atoi(e) != 0; }();
-#define COS(DKV, BF)                                                                                    \
-  rc = KP == KNN_KP_SMALL ? launch_cosine_pass1<DKV, KNN_CAP_SMALL, KNN_KP_SMALL, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st) \
-     : KP == 32 ? launch_cosine_pass1<DKV, 48, 32, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)           \
-                : launch_cosine_pass1<DKV, 128, 64, BF>(qn_query, qn_cand, Nq, Nc, w, &nsplit, st)
-  if (d == 256) { COS(32, false); }            // 256-wide rows keep the fp32 MFMA path (LDS budget)
-  else if (bf3) { if (d == 32) { COS(4, true); } else if (d == 64) { COS(8, true); } else { COS(16, true); } }
-  else { if (d == 32) { COS(4, false); } else if (d == 64) { COS(8, false); } else { COS(16, false); } }
-#undef COS
-  if (rc) return rc;
-  // |fp32 MFMA dot - exact| <= d * 2^-24 * sum|a_c b_c| <= d * 2^-24 for unit vectors (Cauchy-Schwarz);
-  // x2 safety + the fp32 rounding of the stored shortlist score
-  // bf16 path: an operand kept as two pieces is exact to 2^-18 relative, as three pieces to 2^-27; for unit vectors the
-  // score error is <= (sum of the operands' piece errors + the dropped mid*mid term 2^-18) + d 2^-23 for the fp32
-  // accumulation inside the MFMA (counted as truncating).  Two pieces on both sides: 3 * 2^-18 + d 2^-23 = 2.7e-5 at
-  // d = 128; err_abs = 2^-16 + 4 (d + 2) 2^-24 = 4.6e-5 keeps a factor ~2 of safety like the fp32 bound does.
-  const double err_abs = (bf3 && d != 256) ? (CPIECES > 2 ? 0.0 : 1.52587890625e-05) + 4.0 * (double)(d + 2) * 5.9604644775390625e-08
-                                           : 2.0 * (double)(d + 2) * 5.9604644775390625e-08;
+  TopkWs w;
+  topk_ws_layout(Nq, Nc, k, d, &w, ws);
+  hipError_t e;
+  if ((e = hipMemsetAsync(w.counts, 0, 256, st)) != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(w.mx, 0, 256, st)) != hipSuccess) return (int)e;
+  // stage 0: bf16 pieces + residual maxima
+  const int lpr = d / 4;
+  auto split_grid = [&](int64_t n) { const int64_t g = (n * lpr + 255) / 256; return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024); };
+  hipLaunchKernelGGL(split_rows_kernel, dim3(split_grid(Nc)), dim3(256), 0, st, qn_cand, Nc, d, w.ch, w.cm, w.mx);
+  BGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(split_rows_kernel, dim3(split_grid(Nq)), dim3(256), 0, st, qn_query, Nq, d, w.qh, w.qm, w.mx + 2);
+  BGNN_LAUNCH_CHECK();
+  static const int fast_nprod = [] { const char* s = getenv("BGNN_KNN_FAST_PRODUCTS"); const int v = s ? atoi(s) : 1; return v >= 1 && v <= 3 ? v : 1; }();
+  const EpsSrc eps{w.mx, d};
   CosineCanon canon{qn_query, qn_cand, d};
-  return run_refine(canon, Nq, Nc, k, KP, nsplit, w, err_abs, 0.0, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
+  int rc;
+  const int cus = device_cus();
+  if (cus < 1) return (int)hipErrorInvalidDevice;
+  // stage 1 + 2: fast pass over every row, refine.  Most admissions of a streaming top-k happen while the thresholds are
+  // still low, i.e. at the start of every stream (K ln(n/K) in all, two thirds of them in the first sixteenth): a HEAD
+  // pass over the first ~1/16 of the candidates pays that price once, and the MAIN pass over the rest starts every
+  // segment from the head's per-query threshold (a valid lower bound of the final one) instead of from -inf.
+  {
+    const int kp = geom_fast(k).kp;
+    int qpb = 0;
+    P1Params p{w.qh, w.qm, w.ch, w.cm, Nq, Nc, nullptr, nullptr, 0, 0, w.sl_score, w.sl_idx, w.sl_tau, eps, k, 0, 0, nullptr, 0, 0};
+    pass1_any(d, fast_nprod, k, p, nullptr, &qpb, st);
+    const int64_t ntiles = (Nc + CT - 1) / CT;
+    const int64_t head_tiles = ntiles >= 256 ? (ntiles + 15) / 16 : 0;          // small problems: one pass
+    const int64_t NcA = head_tiles * CT, NcB = Nc - NcA;
+    const Pass1Plan plA = head_tiles ? plan_pass1(Nq, NcA, cus, qpb) : Pass1Plan{0, 0, 0};
+    const Pass1Plan plB = plan_pass1(Nq, NcB, cus, qpb);
+    const int nslots = plA.nslots + plB.nslots;
+    if ((rc = init_shortlists(w.sl_idx, Nq * nslots * (int64_t)kp, w.sl_tau, Nq * (int64_t)nslots, st))) return rc;
+    p.nslots = nslots;
+    if (head_tiles) {
+      p.Nc = NcA; p.cand_lo = 0; p.slot_base = 0; p.tau_init = nullptr; p.carry_slots = 0; p.known_tiles = 0;
+      if ((rc = pass1_any(d, fast_nprod, k, p, &plA, nullptr, st))) return rc;
+      hipLaunchKernelGGL(tau_from_slots_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, st, w.sl_tau, Nq, nslots, 0, plA.nslots, w.tau_init);
+      BGNN_LAUNCH_CHECK();
+    }
+    p.Nc = NcB; p.cand_lo = NcA; p.slot_base = plA.nslots; p.tau_init = head_tiles ? w.tau_init : nullptr; p.carry_slots = plA.nslots; p.known_tiles = (int)head_tiles;
+    if ((rc = pass1_any(d, fast_nprod, k, p, &plB, nullptr, st))) return rc;
+    RefineParams rp{Nq, nullptr, nullptr, k, nslots * kp, kp, nslots, w.sl_score, w.sl_idx, w.sl_tau, eps, fast_nprod, 0.0, 0.0,
+                    apply_sigmoid, idx_out, val_out, w.fail1, w.counts};
+    if ((rc = launch_refine(canon, rp, st))) return rc;
+  }
+  // stage 3: precise pass on the rows the fast stage could not prove (plan made on the device from the row count)
+  if (fast_nprod != 3) {
+    const int kp2 = geom_precise(k).kp;
+    P1Params p{w.qh, w.qm, w.ch, w.cm, Nq, Nc, w.fail1, w.counts, 0, MAX_SLOTS, w.sl2_score, w.sl2_idx, w.sl2_tau, eps, k, 0, 0, nullptr, 0, 0};
+    if ((rc = init_shortlists(w.sl2_idx, Nq * MAX_SLOTS * (int64_t)kp2, w.sl2_tau, Nq * MAX_SLOTS, st))) return rc;
+    if ((rc = pass1_any(d, 3, k, p, nullptr, nullptr, st))) return rc;
+    RefineParams rp{Nq, w.fail1, w.counts, k, MAX_SLOTS * kp2, kp2, MAX_SLOTS, w.sl2_score, w.sl2_idx, w.sl2_tau, eps, 3, 0.0, 0.0,
+                    apply_sigmoid, idx_out, val_out, w.fail2, w.counts + 1};
+    if ((rc = launch_refine(canon, rp, st))) return rc;
+  } else {
+    hipLaunchKernelGGL(copy_counts_kernel, dim3(1), dim3(1), 0, st, w.counts, nullptr, w.counts + 1);
+    BGNN_LAUNCH_CHECK();
+    if ((e = hipMemcpyAsync(w.fail2, w.fail1, sizeof(int32_t) * (Nq + 1), hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+  }
+  // stage 4: exhaustive canonical pass for what is left (exact ties across the boundary)
+  hipLaunchKernelGGL((fallback_kernel<CosineCanon>), dim3(w.fb_blocks), dim3(256), 0, st, canon, Nc, k, apply_sigmoid,
+                     w.fail2, w.counts + 1, w.scratch, idx_out, val_out);
+  BGNN_LAUNCH_CHECK();
+  if (n_fallback_opt) {
+    hipLaunchKernelGGL(copy_counts_kernel, dim3(1), dim3(1), 0, st, w.counts + 1, fast_nprod != 3 ? w.counts : nullptr, n_fallback_opt);
+    BGNN_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query, const float* bn_scale,
@@ -1144,40 +1070,50 @@ extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query,
   if (H != MLP_H) return BGNN_E_SHAPE;   // Similar_v2 'mlp' hidden width is fixed at 128 (models.py:921)
   if (k <= 0 || k > 56 || k > Nc) return BGNN_E_RANGE;
   if (!bgnn_aligned16(A_cand) || !bgnn_aligned16(B_query)) return BGNN_E_ALIGN;
-  if (ws_bytes < topk_ws_bytes(Nq, Nc, k)) return BGNN_E_WORKSPACE;
+  if (ws_bytes < topk_ws_layout(Nq < 1 ? 1 : Nq, Nc, k, 32, nullptr, nullptr)) return BGNN_E_WORKSPACE;
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  TopkWs w = topk_carve(ws, Nq, Nc, k);
-  const int epl = k <= 24 ? 1 : 2;
-  const int KP = 32 * epl;
+  TopkWs w;
+  topk_ws_layout(Nq, Nc, k, 32, &w, ws);
+  hipError_t e;
+  if ((e = hipMemsetAsync(w.counts, 0, 256, st)) != hipSuccess) return (int)e;
+  // fp32 evaluation of a 128-term sum of O(1) terms: relative bound on the logit magnitude plus an absolute floor;
+  // generous (a loose bound only widens the shortlist / costs a few more exhaustive rows)
+  const float err_abs = 1e-4f, err_rel = 1e-4f;
+  const Geom g = geom_mlp(k);
+  int rc;
+  if ((rc = init_shortlists(w.sl_idx, Nq * (int64_t)g.kp, w.sl_tau, Nq, st))) return rc;
   {
-    const size_t sh = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H) +
-                      WAVES * (epl == 1 ? WaveTopK<64, 32>::BYTES : WaveTopK<128, 64>::BYTES);
-    const unsigned grid = (unsigned)((Nq + QPB - 1) / QPB);
-    hipError_t e;
-    if (epl == 1) {
-      auto kern = mlp_pass1_kernel<1>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)) != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, w.sl_score, w.sl_idx);
+    const size_t stage = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H);
+    const unsigned grid = (unsigned)((Nq + MLP_WAVES * QPW - 1) / (MLP_WAVES * QPW));
+    if (g.cap == 64) {
+      auto kern = mlp_pass1_kernel<64, 40>;
+      const size_t sh = stage + MLP_WAVES * WaveTopK<64, 40>::BYTES;
+      static int done[BGNN_MAX_DEVICES];
+      if ((e = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)sh, done)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, (int)k, err_abs, err_rel,
+                         w.sl_score, w.sl_idx, w.sl_tau);
     } else {
-      auto kern = mlp_pass1_kernel<2>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)) != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, w.sl_score, w.sl_idx);
+      auto kern = mlp_pass1_kernel<128, 112>;
+      const size_t sh = stage + MLP_WAVES * WaveTopK<128, 112>::BYTES;
+      static int done[BGNN_MAX_DEVICES];
+      if ((e = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)sh, done)) != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sh, st, A_cand, B_query, bn_scale, bn_shift, w2, b2, Nq, Nc, (int)k, err_abs, err_rel,
+                         w.sl_score, w.sl_idx, w.sl_tau);
     }
     BGNN_LAUNCH_CHECK();
   }
-  // fp32 evaluation of a 128-term sum of O(1) terms: relative bound on the logit magnitude plus an
-  // absolute floor; generous (a loose bound only costs a few more exhaustive rows)
   MlpCanon canon{A_cand, B_query, bn_scale, bn_shift, w2, b2, H};
-  return run_refine(canon, Nq, Nc, k, KP, 1, w, 1e-4, 1e-4, apply_sigmoid, idx_out, val_out, n_fallback_opt, st);
+  RefineParams rp{Nq, nullptr, nullptr, k, g.kp, g.kp, 1, w.sl_score, w.sl_idx, w.sl_tau, EpsSrc{nullptr, 0}, 0, (double)err_abs, (double)err_rel,
+                  apply_sigmoid, idx_out, val_out, w.fail2, w.counts + 1};
+  if ((rc = launch_refine(canon, rp, st))) return rc;
+  hipLaunchKernelGGL((fallback_kernel<MlpCanon>), dim3(w.fb_blocks), dim3(256), 0, st, canon, Nc, k, apply_sigmoid,
+                     w.fail2, w.counts + 1, w.scratch, idx_out, val_out);
+  BGNN_LAUNCH_CHECK();
+  if (n_fallback_opt) {
+    hipLaunchKernelGGL(copy_counts_kernel, dim3(1), dim3(1), 0, st, w.counts + 1, nullptr, n_fallback_opt);
+    BGNN_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
-#if defined(KNN_EXP) && (KNN_EXP == 8 || KNN_EXP == 9 || KNN_EXP == 10)
-extern "C" int bgnn_debug_knn_blocks(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_knn_blk), sizeof(unsigned long long) * 1024 * 3);
-}
-extern "C" int bgnn_debug_knn_counters(unsigned long long* host_out) {
-  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_knn_cnt), sizeof(unsigned long long) * 8);
-  return (int)e;
-}
-#endif

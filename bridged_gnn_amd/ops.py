@@ -383,7 +383,7 @@ def _pad_cols(t, d):
 
 def cosine_topk(qn_query, qn_cand, k, apply_sigmoid=True):
     """Top-k cosine neighbours of every query among the candidates (both already L2-normalised).
-    -> (idx int64 [Nq,k], val fp32 [Nq,k], n_fallback int32[1])."""
+    -> (idx int64 [Nq,k], val fp32 [Nq,k], n_fallback int32[2] = (rows re-done exhaustively, rows sent to the precise pass))."""
     lib = L.lib()
     d = qn_query.shape[1]
     dk = next((c for c in _COS_D if c >= d), None)
@@ -394,7 +394,7 @@ def cosine_topk(qn_query, qn_cand, k, apply_sigmoid=True):
     dev = qq.device
     idx = torch.empty(Nq, k, dtype=torch.int64, device=dev)
     val = torch.empty(Nq, k, dtype=torch.float32, device=dev)
-    nfb = torch.zeros(1, dtype=torch.int32, device=dev)
+    nfb = torch.zeros(2, dtype=torch.int32, device=dev)
     wsb = lib.bgnn_topk_workspace_bytes(Nq, Nc, k)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     rc = lib.bgnn_cosine_topk_f32(L.ptr(qq), L.ptr(qc), Nq, Nc, dk, k, 1 if apply_sigmoid else 0, L.ptr(idx),
@@ -409,7 +409,7 @@ def mlp_pair_topk(A_cand, B_query, bn_scale, bn_shift, w2, b2, k, apply_sigmoid=
     dev = A_cand.device
     idx = torch.empty(Nq, k, dtype=torch.int64, device=dev)
     val = torch.empty(Nq, k, dtype=torch.float32, device=dev)
-    nfb = torch.zeros(1, dtype=torch.int32, device=dev)
+    nfb = torch.zeros(2, dtype=torch.int32, device=dev)
     wsb = lib.bgnn_topk_workspace_bytes(Nq, Nc, k)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     rc = lib.bgnn_mlp_pair_topk_f32(L.ptr(A_cand), L.ptr(B_query), L.ptr(bn_scale), L.ptr(bn_shift), L.ptr(w2),

@@ -225,10 +225,14 @@ int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s
  * Selection rule (declared; replaces torch's unspecified tie order): the k candidates with the
  * largest CANONICAL score, ties -> lower candidate index; rows come out sorted by that rule.
  * CANONICAL score = fp64 accumulation in feature-index order of the exact fp32 products
- * (oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk): pass 1 streams all candidates with fp32
- * MFMA (cosine) / fp32 VALU (mlp) keeping a k+margin shortlist per query, pass 2 re-scores the
- * shortlist in canonical arithmetic and proves (by an error-bound margin) that it contains the
- * exact top-k; rows that cannot be proven are re-done exhaustively (counted in n_fallback_opt).
+ * (oracle/oracle_c.c orc_cosine_topk / orc_mlp_topk).  Cosine: a cascade of filters with a proof per stage --
+ * (0) every fp32 embedding is split exactly into bf16 pieces and the residual norms give a rigorous bound eps on
+ * |approximate - exact| score; (1) a FAST pass streams all candidates on the bf16 matrix cores with one piece per
+ * candidate, keeping per query the candidates within 2 eps of the running k-th best; (2) the survivors are re-scored
+ * in canonical arithmetic and the row is proven (kth_exact > best excluded approximate score + eps) or queued;
+ * (3) queued rows go through a PRECISE pass (three piece products, eps ~ 5e-5) and the same proof; (4) rows that are
+ * still unproven (exact ties across the boundary) are re-done exhaustively.  mlp: fp32 VALU pass + stages (2), (4).
+ * n_fallback_opt (optional, int32[2] on the device): [0] = rows re-done exhaustively, [1] = rows sent to the precise pass.
  * val_out = sigmoid(score) as fp32 if apply_sigmoid (models.py:129,:953) else the fp32 score.
  * k <= 56.  q* must already be L2-normalised by bgnn_l2_normalize_rows_f32 (cosine).          */
 int bgnn_l2_normalize_rows_f32(const float* q, int64_t n, int32_t d, float eps, float* out, void* stream);

@@ -170,7 +170,7 @@ class _OracleKnnBackend:
     def cosine_topk(qn, cn, k, apply_sigmoid=True):
         val, idx = OC.cosine_topk(qn.numpy(), cn.numpy(), k)
         v = O.sigmoid_f32(val) if apply_sigmoid else val.astype(np.float32)
-        return torch.from_numpy(idx), torch.from_numpy(v), torch.zeros(1, dtype=torch.int32)
+        return torch.from_numpy(idx), torch.from_numpy(v), torch.zeros(2, dtype=torch.int32)
 
     @staticmethod
     def topk_edges(idx, cand_base=0, query_base=0):
