@@ -11,9 +11,9 @@ kNN-bridge pairs/s (config C5) as an extra field.  One JSON line on rank 0.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one full-graph eval forward with inputs resident in HBM.  N>1: the SAME graph is
-node-partitioned over the ranks (strong scaling): two small all-reduces (domain sums) and one
-all_to_all of the classifier stage's halo rows per forward over RCCL; the halo rows of the input
-features (static data, like the graph) live next to a rank's own rows and are transformed locally.
+node-partitioned over the ranks (strong scaling): one small all-reduce (domain sums of the hidden
+activations) and one all_to_all of the classifier stage's halo rows per forward over RCCL; the halo rows and
+the all-reduced domain sums of the input features (static data, like the graph) stay resident per version of x.
 After the eager measurement the same K steps are timed as replays of a HIP graph of the forward
 (outputs checked against the eager ones); the faster execution is `value`, both are in the line.
 `parity` = the timed forward's own outputs against the CPU oracle (all rows at N=1, part of the cpu_baseline leg).
@@ -511,10 +511,10 @@ def main():
         x_local = wl["x"][pk.owned_global].contiguous()          # the same seed on every rank
         wl["x"] = None
         runner = lambda: pk.forward(x_local)
-        par = (f"dst-node-partition x{world}; per forward 2 small all-reduces (domain sums) + 1 all_to_all of the classifier "
-               f"stage's 48-byte halo rows; " +
-               ("halo rows of the static input features resident (fetched once per version of x), transformed locally"
-                if not args.no_input_halo_cache else "hidden conv's 512-byte halo rows exchanged every forward"))
+        par = (f"dst-node-partition x{world}; per forward 1 small all-reduce (domain sums of h and T(h)) + 1 all_to_all of the "
+               f"classifier stage's 48-byte halo rows; " +
+               ("halo rows and all-reduced domain sums of the static input features resident (fetched once per version of x)"
+                if not args.no_input_halo_cache else "hidden conv: domain-sum all-reduce + 512-byte halo rows exchanged every forward"))
 
     dt, gpu_out = time_forward(runner, args.steps, args.warmup, barrier, timer)
     if use_dist:

@@ -459,7 +459,7 @@ class KTGNN_no_complement(nn.Module):
                 if arena is None:                      # every float64 accumulator of this forward from one zero fill
                     arena = ops.ZeroArena(x.device, (len(self.convs) + 3) * (2 * ops.pad4(max(x.shape[1], conv.out_channels)) + 2))
                 if sums_in is None and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0:
-                    sums_in = ops.domain_sums(x, _as_u8(central_mask).contiguous(), out=arena.take(2 * x.shape[1] + 2))
+                    sums_in = self._input_domain_sums(x, central_mask, arena)
                 if not (conv.root_weight or conv.normalize):
                     sums = arena.take(2 * ops.pad4(conv.out_channels) + 2)
                 x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
@@ -471,6 +471,20 @@ class KTGNN_no_complement(nn.Module):
                 x = F.dropout(x, p=self.dropout, training=self.training)
         self._arena = arena
         return (x, sums) if want_sums else x
+
+    def _input_domain_sums(self, x, central_mask, arena):
+        """Per-domain column sums of the graph's INPUT features (KTGNN.py:275 of the first conv).  `data.x` is static data
+        like the graph (the reference runs 300 epochs x 3 forwards on one `data.x`), so the sums are cached against the
+        tensor objects and their in-place versions: an unchanged x is not streamed again (0.11 ms of a 2.2 ms forward on
+        C4); a new tensor or an in-place write recomputes them."""
+        if torch.cuda.is_current_stream_capturing():          # a captured forward must re-read x on every replay
+            return ops.domain_sums(x, _as_u8(central_mask).contiguous(), out=arena.take(2 * x.shape[1] + 2))
+        c = getattr(self, "_xsum_cache", None)
+        if (c is not None and c[0]() is x and c[1] == x._version and c[2]() is central_mask and c[3] == central_mask._version):
+            return c[4]
+        sums = ops.domain_sums(x, _as_u8(central_mask).contiguous(), out=arena.take(2 * x.shape[1] + 2)).clone()
+        self._xsum_cache = (weakref.ref(x), x._version, weakref.ref(central_mask), central_mask._version, sums)
+        return sums
 
     def _fold_transformer(self):
         """eval BatchNorm of clf_transformer folded into its first Linear (re-folded when a parameter / buffer changes)."""

@@ -270,3 +270,26 @@ def test_c4_full_size_forward_real_attention_vs_oracle():
     # the checksums bench.py prints for the timed forward are those of this output
     sums = [float(np.asarray(o, np.float64).sum()) for o in out]
     assert np.allclose(sums, [float(np.asarray(r, np.float64).sum()) for r in (rb, rt, rth)], rtol=1e-6)
+
+
+def test_input_domain_sums_cache_follows_x():
+    """the cached domain sums of the (static) input features are dropped when x is written in place or replaced"""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    ei, mask = synth.random_multigraph(800, 6000, seed=3)
+    torch.manual_seed(0)
+    model = KTGNN_no_complement(32, 3, 2, 64, use_bn=True, dim_share=32).to(DEV).eval()
+    x = torch.randn(800, 32, device=DEV)
+    data = Data(x=x, edge_index=_t(ei), central_mask=_t(mask))
+    with torch.no_grad():
+        a = [t.clone() for t in model(data)[:3]]
+        b = model(data)[:3]                                   # second call: sums come from the cache
+        close = lambda u, v: torch.allclose(u, v, rtol=1e-6, atol=1e-6)   # (the fp64 column-sum atomics are not ordered run to run)
+        assert all(close(u, v) for u, v in zip(a, b))
+        x.mul_(1.5)                                           # in-place edit: new version
+        c = [t.clone() for t in model(data)[:3]]
+        fresh = KTGNN_no_complement(32, 3, 2, 64, use_bn=True, dim_share=32).to(DEV).eval()
+        fresh.load_state_dict(model.state_dict())
+        d = fresh(Data(x=x.clone(), edge_index=_t(ei), central_mask=_t(mask)))[:3]
+        assert all(close(u, v) for u, v in zip(c, d)) and not close(a[0], c[0])
