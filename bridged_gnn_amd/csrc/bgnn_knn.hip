@@ -98,7 +98,7 @@ struct WaveTopK {
   unsigned base;                         // byte offset of this wave's state in knn_smem
   int k;                                 // wanted neighbours
   float margin_abs, margin_rel;          // margin(a) = margin_abs + margin_rel * |a|
-  __device__ __forceinline__ uint32_t* skey() const { return reinterpret_cast<uint32_t*>(knn_smem + base); }            // [QPW][CAP] ord(score)
+  __device__ __forceinline__ uint32_t* skey() const { return reinterpret_cast<uint32_t*>(knn_smem + base); }            // [QPW][CAP] score bits
   __device__ __forceinline__ uint32_t* sidx() const { return skey() + QPW * CAP; }                                      // [QPW][CAP] candidate
   __device__ __forceinline__ int* cnt() const { return reinterpret_cast<int*>(sidx() + QPW * CAP); }                    // [QPW]
   __device__ __forceinline__ float* tau() const { return reinterpret_cast<float*>(cnt() + QPW); }                       // [QPW]
@@ -123,7 +123,7 @@ struct WaveTopK {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const int i = lane + 64 * e;
-      s[e] = i < n ? skey()[q * CAP + i] : ORD_EMPTY;          // empty slots carry 0 < ord(-inf)
+      s[e] = i < n ? ord_f32(__uint_as_float(skey()[q * CAP + i])) : ORD_EMPTY;      // empty slots carry 0 < ord(-inf)
       x[e] = sidx()[q * CAP + i];
       smax = s[e] > smax ? s[e] : smax;
     }
@@ -168,7 +168,7 @@ struct WaveTopK {
       const unsigned long long b = __ballot(kp);
       if (kp) {
         const int pos = before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        skey()[q * CAP + pos] = s[e];
+        skey()[q * CAP + pos] = __float_as_uint(unord_f32(s[e]));
         sidx()[q * CAP + pos] = x[e];
       }
       before += __popcll(b);
@@ -203,7 +203,7 @@ __device__ __noinline__ void insert_overflow(TK tk, bool pend, uint32_t so, uint
       over &= ~__ballot(pend && q == qsel);
     }
     compact_rows(tk, qmask, lane);
-    pend = pend && unord_f32(so) > tk.tau()[q];
+    pend = pend && __uint_as_float(so) > tk.tau()[q];
     if (pend) {
       const int slot = atomicAdd(&tk.cnt()[q], 1);
       if (slot < CAP) { tk.skey()[q * CAP + slot] = so; tk.sidx()[q * CAP + slot] = cand; pend = false; }
@@ -235,7 +235,7 @@ __device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_
   for (int r = 0; r < 16; ++r) {
     const bool hit = acc[r] > tau;
     if (__any(hit)) {                               // wave-uniform
-      const uint32_t so = ord_f32(acc[r]);
+      const uint32_t so = __float_as_uint(acc[r]);    // raw bits; the ordered form is made where entries are compared
       const uint32_t cand = (uint32_t)(cand_lo + cbase + (r & 3) + 8 * (r >> 2) + 4 * h);
       bool pend = hit;
       if (hit) {
@@ -267,7 +267,7 @@ __device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, in
         if (pos < KP) {
           const int64_t o = (gq * nslots + slot) * KP + pos;
           const bool own = pos < n && tk.sidx()[q * CAP + pos] >= cand_lo;        // seeds of the head pass stay in its slots
-          sl_score[o] = own ? unord_f32(tk.skey()[q * CAP + pos]) : -INFINITY;
+          sl_score[o] = own ? __uint_as_float(tk.skey()[q * CAP + pos]) : -INFINITY;
           sl_idx[o] = own ? (int32_t)tk.sidx()[q * CAP + pos] : -1;
         }
       }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
           const bool kp = c >= 0 && sc > t0;
           const unsigned long long b = __ballot(kp);
           const int pos = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-          if (kp && pos < CAPV) { tk.skey()[qq * CAPV + pos] = ord_f32(sc); tk.sidx()[qq * CAPV + pos] = (uint32_t)c; }
+          if (kp && pos < CAPV) { tk.skey()[qq * CAPV + pos] = __float_as_uint(sc); tk.sidx()[qq * CAPV + pos] = (uint32_t)c; }
           have += __popcll(b);
         }
         if (lane == 0) tk.cnt()[qq] = have < CAPV ? have : CAPV;
@@ -520,11 +520,16 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
     // compacting EVERY buffer when g crosses 2, 3, 5, 8, 13, ... (x 1.6) keeps the expected arrivals between two
     // compactions at K ln 1.6 ~ 16 < the buffers' slack: the waves compact at the same tiles and stay in step.
     int next_c = p.known_tiles > 0 ? p.known_tiles + (p.known_tiles * KNN_SCHED_NUM >> 3) : 2;
+    // The two waves of a SIMD (w and w + NW/2) run the halves of an iteration in OPPOSITE order: one issues its MFMA chain
+    // while the other does its shortlist upkeep (VALU / LDS), then they swap -- in lock step behind the tile barrier both
+    // would otherwise queue on the matrix pipe first and on the vector issue afterwards.
+    const bool mfma_first = wave < NW / 2 || NW == 1;
     for (int i = 0; i < nt; ++i, cur ^= 1) {
-      const f32x16 accN = score(cur);                   // tile ct0+i: LDS reads + MFMA chain issued first ...
+      f32x16 accN;
+      if (mfma_first) accN = score(cur);                // tile ct0+i: LDS reads + MFMA chain
       if (i + 1 < nt) sstore(cur ^ 1);                  // tile i+1: registers -> the buffer tile i-1 was read from
       if (i + 2 < nt) gload(ct0 + i + 2);               // tile i+2 flies
-      if (i > 0) {                                      // ... the upkeep of tile i-1 runs beside them
+      if (i > 0) {                                      // the upkeep of tile i-1
         offer_tile(tk, accP, (int)(ct0 + i - 1) * CT, p.Nc, (int)p.cand_lo, lane, tau);
         if (p.known_tiles + i >= next_c) {
           // only the buffers that could fill before the next scheduled compaction (the others keep their slack)
@@ -534,6 +539,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
           next_c += (next_c * KNN_SCHED_NUM >> 3) > 0 ? (next_c * KNN_SCHED_NUM >> 3) : 1;
         }
       }
+      if (!mfma_first) accN = score(cur);
       __syncthreads();                                  // stage[cur^1] complete; nobody reads stage[cur] any more
       accP = accN;
     }
