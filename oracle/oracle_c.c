@@ -119,6 +119,51 @@ void orc_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, const
   }
 }
 
+/* The same aggregation with every intermediate in fp64 (inputs are the fp32 tables): the real-arithmetic value of the
+ * reference's formula on those inputs, to ~1e-15.  Used to split the parity budget: |GPU - truth| and |fp32 oracle -
+ * truth| are measured separately (tests/test_gpu_ktgnn.py), so a tolerance never has to absorb the CHECKER's own
+ * fp32 rounding. */
+void orc_adaptedconv_aggregate_f64(const float* h_t2s, const float* h_s2t, const float* a_t2s,
+                                   const float* a_s2t, const int32_t* rowptr, const int32_t* col,
+                                   const uint8_t* mask, int64_t N, int32_t D, int64_t ldh,
+                                   float slope, double* out, int64_t ldo) {
+#pragma omp parallel
+  {
+    int cap = 1024;
+    double* e = (double*)malloc(sizeof(double) * cap);
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+      const float* H = mask[i] ? h_t2s : h_s2t;
+      const float* a = mask[i] ? a_t2s : a_s2t;
+      const float* hi = H + i * ldh;
+      int32_t b = rowptr[i], en = rowptr[i + 1], deg = en - b;
+      if (deg > cap) { cap = deg * 2; e = (double*)realloc(e, sizeof(double) * cap); }
+      double m = -INFINITY;
+      for (int32_t t = 0; t < deg; ++t) {
+        const float* hj = H + (int64_t)col[b + t] * ldh;
+        double s = 0.0;
+        for (int c = 0; c < D; ++c) {
+          double v = (double)hj[c] + (double)hi[c];
+          v = v > 0.0 ? v : (double)slope * v;
+          s += v * (double)a[c];
+        }
+        e[t] = s;
+        if (s > m) m = s;
+      }
+      double sum = 0.0;
+      for (int32_t t = 0; t < deg; ++t) { e[t] = exp(e[t] - m); sum += e[t]; }
+      double* o = out + i * ldo;
+      for (int c = 0; c < D; ++c) o[c] = 0.0;
+      for (int32_t t = 0; t < deg; ++t) {
+        double al = e[t] / (sum + 1e-16);
+        const float* hj = H + (int64_t)col[b + t] * ldh;
+        for (int c = 0; c < D; ++c) o[c] += (double)hj[c] * al;
+      }
+    }
+    free(e);
+  }
+}
+
 /* CANONICAL row normalisation (shared bit-for-bit with the HIP kernel): fp64 sum of squares in
  * index order, fp64 sqrt, round to fp32, clamp at eps, one IEEE fp32 divide per element.
  * Real-arithmetic meaning: CosineSimilarity(dim=1, eps=1e-8), models/models.py:127. */

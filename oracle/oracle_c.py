@@ -69,6 +69,20 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, slope=0
     return (out, alpha) if want_alpha else out
 
 
+def adaptedconv_aggregate_f64(h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, slope=0.1):
+    """every intermediate in fp64 (inputs fp32): the real-arithmetic value of the reference's formula"""
+    h_t2s, h_s2t = _f32(h_t2s), _f32(h_s2t)
+    N, D = h_t2s.shape
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    cl = np.ascontiguousarray(col, dtype=np.int32)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty((N, D), np.float64)
+    lib().orc_adaptedconv_aggregate_f64(_p(h_t2s), _p(h_s2t), _p(_f32(a_t2s).reshape(-1)), _p(_f32(a_s2t).reshape(-1)),
+                                        _p(rp), _p(cl), _p(m), C.c_int64(N), C.c_int32(D), C.c_int64(D),
+                                        C.c_float(slope), _p(out), C.c_int64(D))
+    return out
+
+
 def l2_normalize_rows(q, eps=1e-8):
     q = _f32(q)
     out = np.empty_like(q)

@@ -165,10 +165,17 @@ def test_aggregate_fuzz_vs_c_oracle(seed):
     sc = _t(rng.uniform(0.5, 1.5, D).astype(np.float32)); sh = _t(rng.standard_normal(D).astype(np.float32))
     out = ops.adaptedconv_aggregate(tS, tT, _t(a1), _t(a2), csr, m8, D, slope, ep_scale=sc, ep_shift=sh, ep_relu=True, colsum=sums)
     rowptr, col, _ = O.dst_csr(ei, mask)
+    # The checker is the fp64 evaluation of the reference's formula (the real-arithmetic value on these fp32 inputs):
+    # the GPU result meets the 1e-5 / 1e-6 bar against THAT on every seed.  The fp32 oracle -- the reference's own
+    # precision, a serial fp32 sum over the 3000-edge hub row -- does not (4 of 24 seeds, up to 1.7e-5 absolute on
+    # |ref| ~ 6): the 2e-5 / 4e-6 tolerance of round 1 was absorbing the CHECKER's fp32 rounding, not a kernel error.
+    truth = OC.adaptedconv_aggregate_f64(hS, hT, a1, a2, rowptr, col, mask, slope=slope)
+    truth = np.maximum(truth * sc.cpu().numpy().astype(np.float64) + sh.cpu().numpy().astype(np.float64), 0.0)
     ref = OC.adaptedconv_aggregate(hS, hT, a1, a2, rowptr, col, mask, slope=slope)
     ref = np.maximum(ref * sc.cpu().numpy() + sh.cpu().numpy(), 0.0)
     got = out[:, :D].cpu().numpy()
-    assert_close(got, ref, rtol=2e-5, atol_scale=4e-6, what=f"fuzz seed={seed} D={D} n={n} slope={slope}")
+    assert_close(got, truth, what=f"GPU vs fp64 truth, fuzz seed={seed} D={D} n={n} slope={slope}")
+    assert_close(ref, truth, rtol=2e-5, atol_scale=4e-6, what=f"fp32 oracle vs fp64 truth, fuzz seed={seed} D={D} n={n} slope={slope}")
     s = sums.cpu().numpy()
     np.testing.assert_allclose(s[:D], got[mask].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(s[ld:ld + D], got[~mask].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
