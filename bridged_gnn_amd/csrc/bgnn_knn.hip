@@ -25,7 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QPW = 32;            // queries per wave (one 32-wide MFMA column block)
-constexpr int CT = 32;             // candidates per MFMA tile
+constexpr int MT = 32;             // candidates per MFMA tile (pass 1 stages TPI of them per barrier)
 constexpr int MAX_SLOTS = 8;       // shortlists per query (blocks whose tile range touches one query block)
 constexpr int LDS_BYTES = 160 * 1024;
 #ifndef KNN_SCHED_NUM
@@ -89,8 +89,8 @@ __device__ __forceinline__ uint32_t bgnn_wave_max_u32(uint32_t x) {
 // Invariant: every candidate that was ever refused or dropped has an approximate score <= tau (tau never decreases).
 template <int CAPV, int KPV>
 struct WaveTopK {
-  static constexpr int CAP = CAPV, KP = KPV, EPL = CAPV / 64;
-  static_assert(CAPV == 64 || CAPV == 128, "one or two buffer entries per lane");
+  static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
+  static_assert(CAPV <= 128 && CAPV % 2 == 0, "one or two buffer entries per lane");
   static_assert(KPV < CAPV, "slack between two compactions");
   static constexpr size_t BYTES = 2 * sizeof(uint32_t) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW;
   // the state is addressed as an OFFSET into the kernel's dynamic LDS (not as generic pointers): the accessors below
@@ -219,7 +219,7 @@ template <class TK>
 __device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int cand_lo, int lane, float& tau) {
   constexpr int CAP = TK::CAP;
   const int q = lane & 31, h = lane >> 5;
-  if (cbase + CT > Nc) {                            // last (partial) tile only: mask candidates >= Nc
+  if (cbase + MT > Nc) {                            // last (partial) tile only: mask candidates >= Nc
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (cbase + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) acc[r] = -INFINITY;
@@ -367,15 +367,16 @@ __device__ __forceinline__ int bf_swz(int row) {          // 16-byte chunk swizz
   else return (row >> 2) & 3;
 }
 
-template <int DK, int NPROD, int CAPV, int KPV, int NW>
+template <int DK, int NPROD, int CAPV, int KPV, int NW, int TPI>
 __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p) {
   typedef WaveTopK<CAPV, KPV> TK;
   constexpr int D = DK * 8, NCH = D / 8, NT = 64 * NW, QB = NW * QPW;
+  constexpr int CT = MT * TPI;                                             // candidates staged (and scored) per barrier
   constexpr int CPIECES = NPROD == 3 ? 2 : 1, QPIECES = NPROD >= 2 ? 2 : 1;
   constexpr int PIECE_ELEMS = CT * D;                                      // bf16 elements of one staged piece
   constexpr int STAGE_ELEMS = CPIECES * PIECE_ELEMS;
   static_assert((size_t)2 * STAGE_ELEMS * 2 + (size_t)NW * TK::BYTES <= (size_t)LDS_BYTES, "LDS budget");
-  __bf16* stage16 = reinterpret_cast<__bf16*>(knn_smem);                   // [2][CPIECES][CT][NCH ^ swizzle][8]
+  __bf16* stage16 = reinterpret_cast<__bf16*>(knn_smem);                   // [2][CPIECES][CT][NCH ^ swizzle][8]  (swizzle by row & 15 ..)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t nq = p.nq_dev ? (int64_t)*p.nq_dev : p.Nq;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
     sstore(0);
     if (ct0 + 1 < ct1) gload(ct0 + 1);
     __syncthreads();
-    auto score = [&](int cur) {
+    auto score = [&](int cur, int sub) {
       // ONE accumulation chain: back-to-back 32x32x16 bf16 MFMAs on one accumulator issue at the pipe's full rate
       // (MI355X_MICROARCH.md, cycle constants), so no second chain and no merge adds
       f32x16 acc;
@@ -493,10 +494,10 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
       const __bf16* st = stage16 + cur * STAGE_ELEMS;
       bf16x8 ahv[D / 16];                             // every A fragment of the tile is requested before the first MFMA waits
 #pragma unroll
-      for (int kb = 0; kb < D / 16; ++kb) ahv[kb] = *reinterpret_cast<const bf16x8*>(&st[(fr * NCH + ((2 * kb + fh) ^ sw)) * 8]);
+      for (int kb = 0; kb < D / 16; ++kb) ahv[kb] = *reinterpret_cast<const bf16x8*>(&st[((sub * MT + fr) * NCH + ((2 * kb + fh) ^ sw)) * 8]);
 #pragma unroll
       for (int kb = 0; kb < D / 16; ++kb) {
-        const int off = (fr * NCH + ((2 * kb + fh) ^ sw)) * 8;
+        const int off = ((sub * MT + fr) * NCH + ((2 * kb + fh) ^ sw)) * 8;
         const bf16x8 ah = ahv[kb];
         f32x16& a = acc;
         // smallest terms first
@@ -509,28 +510,35 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
       }
       return acc;
     };
-    f32x16 accP;
+    f32x16 accP[TPI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accP[r] = -INFINITY;
+    for (int u = 0; u < TPI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accP[u][r] = -INFINITY;
     int cur = 0;
-    const int nt = (int)(ct1 - ct0);                    // tiles of this segment (32-bit loop arithmetic)
+    const int nt = (int)(ct1 - ct0);                    // staged units of this segment (32-bit loop arithmetic)
     // SCHEDULED compactions.  A buffer would otherwise be compacted whenever it happens to fill: ~14 times per query at
     // unpredictable tiles, and every such call (~3000 cycles) holds all eight waves at the tile barrier (measured: 1860
     // of 4400 cycles per wave and tile were barrier wait).  The admission rate of a stream at position g is ~ K / g, so
-    // compacting EVERY buffer when g crosses 2, 3, 5, 8, 13, ... (x 1.6) keeps the expected arrivals between two
-    // compactions at K ln 1.6 ~ 16 < the buffers' slack: the waves compact at the same tiles and stay in step.
+    // compacting the fuller buffers when g crosses 2, 3, 4, 6, 8, 11, ... (x 1.375) keeps the expected arrivals between
+    // two compactions at K ln 1.375 ~ 11 < the buffers' slack: the waves compact at the same tiles and stay in step.
     int next_c = p.known_tiles > 0 ? p.known_tiles + (p.known_tiles * KNN_SCHED_NUM >> 3) : 2;
     // The two waves of a SIMD (w and w + NW/2) run the halves of an iteration in OPPOSITE order: one issues its MFMA chain
     // while the other does its shortlist upkeep (VALU / LDS), then they swap -- in lock step behind the tile barrier both
     // would otherwise queue on the matrix pipe first and on the vector issue afterwards.
     const bool mfma_first = wave < NW / 2 || NW == 1;
     for (int i = 0; i < nt; ++i, cur ^= 1) {
-      f32x16 accN;
-      if (mfma_first) accN = score(cur);                // tile ct0+i: LDS reads + MFMA chain
-      if (i + 1 < nt) sstore(cur ^ 1);                  // tile i+1: registers -> the buffer tile i-1 was read from
-      if (i + 2 < nt) gload(ct0 + i + 2);               // tile i+2 flies
-      if (i > 0) {                                      // the upkeep of tile i-1
-        offer_tile(tk, accP, (int)(ct0 + i - 1) * CT, p.Nc, (int)p.cand_lo, lane, tau);
+      f32x16 accN[TPI];
+      if (mfma_first) {                                 // unit ct0+i: LDS reads + MFMA chains
+#pragma unroll
+        for (int u = 0; u < TPI; ++u) accN[u] = score(cur, u);
+      }
+      if (i + 1 < nt) sstore(cur ^ 1);                  // unit i+1: registers -> the buffer unit i-1 was read from
+      if (i + 2 < nt) gload(ct0 + i + 2);               // unit i+2 flies
+      if (i > 0) {                                      // the upkeep of unit i-1
+#pragma unroll
+        for (int u = 0; u < TPI; ++u)
+          offer_tile(tk, accP[u], (int)(ct0 + i - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau);
         if (p.known_tiles + i >= next_c) {
           // only the buffers that could fill before the next scheduled compaction (the others keep their slack)
           const unsigned long long fullish = __ballot(lane < QPW && tk.cnt()[lane & 31] > CAPV - KNN_SCHED_FREE);
@@ -539,11 +547,17 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
           next_c += (next_c * KNN_SCHED_NUM >> 3) > 0 ? (next_c * KNN_SCHED_NUM >> 3) : 1;
         }
       }
-      if (!mfma_first) accN = score(cur);
+      if (!mfma_first) {
+#pragma unroll
+        for (int u = 0; u < TPI; ++u) accN[u] = score(cur, u);
+      }
       __syncthreads();                                  // stage[cur^1] complete; nobody reads stage[cur] any more
-      accP = accN;
+#pragma unroll
+      for (int u = 0; u < TPI; ++u) accP[u] = accN[u];
     }
-    offer_tile(tk, accP, (int)(ct1 - 1) * CT, p.Nc, (int)p.cand_lo, lane, tau);
+#pragma unroll
+    for (int u = 0; u < TPI; ++u)
+      offer_tile(tk, accP[u], (int)(ct1 - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau);
     emit_shortlists(tk, lane, q0, nq, p.sl_score, p.sl_idx, p.sl_tau, slot, p.nslots, (uint32_t)p.cand_lo);
     t += ct1 - ct0;
   }
@@ -553,6 +567,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
 // pass 1, mlp (Similar_v2 'mlp' in separable eval form, H = 128): fp32 VALU scoring, same shortlist.
 constexpr int MLP_H = 128;
 constexpr int MLP_WAVES = 4;
+constexpr int MLP_CT = MT;          // candidates per staged tile of the mlp pass
 template <int CAPV, int KPV>
 __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -562,12 +577,12 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
                                                            float* __restrict__ sl_tau) {
   typedef WaveTopK<CAPV, KPV> TK;
   constexpr int H = MLP_H, LD = H + 4;
-  float* stage = reinterpret_cast<float*>(knn_smem);                                // [CT][LD]
-  float* coefs = stage + CT * LD;                                                   // scale|shift|w2 [3][H]
+  float* stage = reinterpret_cast<float*>(knn_smem);                                // [MLP_CT][LD]
+  float* coefs = stage + MLP_CT * LD;                                                   // scale|shift|w2 [3][H]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t q0 = (int64_t)blockIdx.x * (MLP_WAVES * QPW) + wave * QPW;
   TK tk;
-  tk.carve((unsigned)(sizeof(float) * (CT * LD + 3 * H) + (size_t)wave * TK::BYTES));
+  tk.carve((unsigned)(sizeof(float) * (MLP_CT * LD + 3 * H) + (size_t)wave * TK::BYTES));
   tk.k = k;
   tk.margin_abs = 2.f * err_abs + 1e-7f;
   tk.margin_rel = 2.f * err_rel;
@@ -585,9 +600,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
   const float4* sc4 = reinterpret_cast<const float4*>(coefs);
   const float4* sh4 = reinterpret_cast<const float4*>(coefs + H);
   const float4* w4 = reinterpret_cast<const float4*>(coefs + 2 * H);
-  for (int64_t cb = 0; cb < Nc; cb += CT) {
+  for (int64_t cb = 0; cb < Nc; cb += MLP_CT) {
     __syncthreads();
-    for (int f = tid; f < CT * (H / 4); f += 256) {
+    for (int f = tid; f < MLP_CT * (H / 4); f += 256) {
       const int r = f / (H / 4), c4 = f % (H / 4);
       const int64_t gc = cb + r;
       *reinterpret_cast<float4*>(&stage[r * LD + c4 * 4]) =
@@ -827,15 +842,15 @@ __global__ void copy_counts_kernel(const int32_t* __restrict__ exhaustive, const
 
 // ------------------------------------------------------------------------------------------------
 // host side: geometry and workspace
-struct Geom { int cap, kp; };                       // shortlist geometry by k
-static Geom geom_fast(int k) { return k <= 20 ? Geom{64, 48} : Geom{128, 112}; }
-static Geom geom_precise(int k) { return k <= 20 ? Geom{64, 32} : Geom{128, 96}; }
-static Geom geom_mlp(int k) { return k <= 24 ? Geom{64, 40} : Geom{128, 112}; }
+struct Geom { int cap, kp, tpi; };                  // shortlist geometry by k; MFMA tiles staged per barrier
+static Geom geom_fast(int k) { return k <= 20 ? Geom{62, 48, 2} : Geom{128, 112, 1}; }     // 62: leaves LDS for 2 x 64-row stages
+static Geom geom_precise(int k) { return k <= 20 ? Geom{64, 32, 1} : Geom{128, 96, 1}; }
+static Geom geom_mlp(int k) { return k <= 24 ? Geom{64, 40, 1} : Geom{128, 112, 1}; }
 static int max_kp(int k) { return geom_fast(k).kp; }
 
 struct Pass1Plan { int64_t nblocks, tpb; int nslots; };
-static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int qpb) {
-  const int64_t ntiles = (Nc + CT - 1) / CT, nqb = (Nq + qpb - 1) / qpb, T = ntiles * nqb;
+static Pass1Plan plan_pass1(int64_t Nq, int64_t Nc, int64_t resident_blocks, int qpb, int ct) {
+  const int64_t ntiles = (Nc + ct - 1) / ct, nqb = (Nq + qpb - 1) / qpb, T = ntiles * nqb;
   Pass1Plan pl;
   pl.nblocks = T < resident_blocks ? T : resident_blocks;
   if (pl.nblocks < 1) pl.nblocks = 1;
@@ -898,18 +913,18 @@ static int device_cus() {
 }
 
 // waves per block of a pass-1 instantiation: the most that fit the 160 KB of LDS next to the double-buffered stage
-template <int DK, int NPROD, int CAPV>
+template <int DK, int NPROD, int CAPV, int TPI>
 constexpr int pass1_waves() {
-  constexpr size_t stage = (size_t)2 * (NPROD == 3 ? 2 : 1) * CT * DK * 8 * 2;
+  constexpr size_t stage = (size_t)2 * (NPROD == 3 ? 2 : 1) * MT * TPI * DK * 8 * 2;
   constexpr size_t per_wave = sizeof(u64) * QPW * CAPV + 2 * 4 * QPW;
   return (stage + 8 * per_wave <= (size_t)LDS_BYTES) ? 8 : (stage + 4 * per_wave <= (size_t)LDS_BYTES) ? 4 : (stage + 2 * per_wave <= (size_t)LDS_BYTES) ? 2 : 1;
 }
 
-template <int DK, int NPROD, int CAPV, int KPV>
+template <int DK, int NPROD, int CAPV, int KPV, int TPI>
 static int launch_pass1(P1Params p, const Pass1Plan* plan /* nullptr: the kernel plans from the device-side row count */, hipStream_t st) {
-  constexpr int NW = pass1_waves<DK, NPROD, CAPV>();
-  constexpr size_t sh = (size_t)2 * (NPROD == 3 ? 2 : 1) * CT * DK * 8 * 2 + (size_t)NW * WaveTopK<CAPV, KPV>::BYTES;
-  auto kern = cosine_pass1_kernel<DK, NPROD, CAPV, KPV, NW>;
+  constexpr int NW = pass1_waves<DK, NPROD, CAPV, TPI>();
+  constexpr size_t sh = (size_t)2 * (NPROD == 3 ? 2 : 1) * MT * TPI * DK * 8 * 2 + (size_t)NW * WaveTopK<CAPV, KPV>::BYTES;
+  auto kern = cosine_pass1_kernel<DK, NPROD, CAPV, KPV, NW, TPI>;
   static int attr_done[BGNN_MAX_DEVICES];
   hipError_t e = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)sh, attr_done);
   if (e != hipSuccess) return (int)e;
@@ -924,14 +939,14 @@ static int launch_pass1(P1Params p, const Pass1Plan* plan /* nullptr: the kernel
 // dispatch over (embedding width, product set, shortlist geometry); `qpb_out` != nullptr only asks for the query rows per block
 template <int DK>
 static int pass1_dk(int nprod, int k, const P1Params& p, const Pass1Plan* plan, int* qpb_out, hipStream_t st) {
-#define BGNN_P1(NP, CAPV, KPV)                                                                         \
+#define BGNN_P1(NP, CAPV, KPV, TPI)                                                                    \
   do {                                                                                                 \
-    if (qpb_out) { *qpb_out = pass1_waves<DK, NP, CAPV>() * QPW; return 0; }                           \
-    return launch_pass1<DK, NP, CAPV, KPV>(p, plan, st);                                               \
+    if (qpb_out) { *qpb_out = pass1_waves<DK, NP, CAPV, TPI>() * QPW; return 0; }                      \
+    return launch_pass1<DK, NP, CAPV, KPV, TPI>(p, plan, st);                                          \
   } while (0)
-  if (nprod == 3) { if (geom_precise(k).cap == 64) BGNN_P1(3, 64, 32); else BGNN_P1(3, 128, 96); }
-  if (nprod == 2) { if (geom_fast(k).cap == 64) BGNN_P1(2, 64, 48); else BGNN_P1(2, 128, 112); }
-  if (geom_fast(k).cap == 64) BGNN_P1(1, 64, 48); else BGNN_P1(1, 128, 112);
+  if (nprod == 3) { if (geom_precise(k).cap == 64) BGNN_P1(3, 64, 32, 1); else BGNN_P1(3, 128, 96, 1); }
+  if (nprod == 2) { if (geom_fast(k).cap == 62) BGNN_P1(2, 62, 48, 2); else BGNN_P1(2, 128, 112, 1); }
+  if (geom_fast(k).cap == 62) BGNN_P1(1, 62, 48, 2); else BGNN_P1(1, 128, 112, 1);
 #undef BGNN_P1
 }
 static int pass1_any(int d, int nprod, int k, const P1Params& p, const Pass1Plan* plan, int* qpb_out, hipStream_t st) {
@@ -1022,11 +1037,12 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
     int qpb = 0;
     P1Params p{w.qh, w.qm, w.ch, w.cm, Nq, Nc, nullptr, nullptr, 0, 0, w.sl_score, w.sl_idx, w.sl_tau, eps, k, 0, 0, nullptr, 0, 0};
     pass1_any(d, fast_nprod, k, p, nullptr, &qpb, st);
-    const int64_t ntiles = (Nc + CT - 1) / CT;
-    const int64_t head_tiles = ntiles >= 256 ? (ntiles + 15) / 16 : 0;          // small problems: one pass
-    const int64_t NcA = head_tiles * CT, NcB = Nc - NcA;
-    const Pass1Plan plA = head_tiles ? plan_pass1(Nq, NcA, cus, qpb) : Pass1Plan{0, 0, 0};
-    const Pass1Plan plB = plan_pass1(Nq, NcB, cus, qpb);
+    const int ct = MT * geom_fast(k).tpi;                                       // candidates per staged unit
+    const int64_t ntiles = (Nc + ct - 1) / ct;
+    const int64_t head_tiles = ntiles >= 128 ? (ntiles + 15) / 16 : 0;          // small problems: one pass
+    const int64_t NcA = head_tiles * ct, NcB = Nc - NcA;
+    const Pass1Plan plA = head_tiles ? plan_pass1(Nq, NcA, cus, qpb, ct) : Pass1Plan{0, 0, 0};
+    const Pass1Plan plB = plan_pass1(Nq, NcB, cus, qpb, ct);
     const int nslots = plA.nslots + plB.nslots;
     if ((rc = init_shortlists(w.sl_idx, Nq * nslots * (int64_t)kp, w.sl_tau, Nq * (int64_t)nslots, st))) return rc;
     p.nslots = nslots;
@@ -1090,7 +1106,7 @@ extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query,
   int rc;
   if ((rc = init_shortlists(w.sl_idx, Nq * (int64_t)g.kp, w.sl_tau, Nq, st))) return rc;
   {
-    const size_t stage = sizeof(float) * (CT * (MLP_H + 4) + 3 * MLP_H);
+    const size_t stage = sizeof(float) * (MLP_CT * (MLP_H + 4) + 3 * MLP_H);
     const unsigned grid = (unsigned)((Nq + MLP_WAVES * QPW - 1) / (MLP_WAVES * QPW));
     if (g.cap == 64) {
       auto kern = mlp_pass1_kernel<64, 40>;
