@@ -669,15 +669,16 @@ struct MlpCanon {
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf(-x)); }
 
 // pass 2: one wave per query.  L = nslots*KP shortlist entries + nslots thresholds.
-//   alast = max over the slots' thresholds = the best approximate score any excluded candidate can have;
-//   survivors = listed candidates with approximate score > alast (a candidate at or below it is dominated by the k
-//   listed candidates of the slot that set alast, whose approximate scores exceed it by the margin 2 eps);
-//   exact re-score + rank of the survivors; proof  kth_exact > alast + bound.
+//   alast = max over the slots' thresholds = the best approximate score any NEVER-LISTED candidate can have;
+//   a_k   = the k-th best approximate score among the listed candidates (bracketed by bisection on the ordered bits);
+//   T     = max(alast, a_k - margin), margin = 2 eps (+ slack): a candidate with approximate score <= T is strictly
+//           dominated by the k candidates at or above a_k (exact >= a_k - eps > T + eps >= its exact score);
+//   survivors = listed candidates above T (~ k + a few): exact re-score + rank; proof  kth_exact > T + eps.
 struct RefineParams {
   int64_t Nq; const int32_t* qlist; const int32_t* nq_dev;
   int k, L, KP, nslots;
   const float* sl_score; const int32_t* sl_idx; const float* sl_tau;
-  EpsSrc eps; int nprod;                 // nprod > 0: bound from the residual maxima; else err_abs + err_rel |alast|
+  EpsSrc eps; int nprod;                 // nprod > 0: bound from the residual maxima; else err_abs + err_rel |T|
   double err_abs, err_rel;
   int apply_sigmoid;
   int64_t* idx_out; float* val_out;
@@ -687,8 +688,10 @@ template <class Canon>
 __global__ __launch_bounds__(256) void refine_kernel(Canon canon, const RefineParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L = p.L;
-  double* es = reinterpret_cast<double*>(knn_smem) + (size_t)wave * L;                    // exact scores of the survivors
+  // per wave: exact scores [L] doubles, candidates [L] ints, ordered approximate scores [L] uints
+  double* es = reinterpret_cast<double*>(knn_smem) + (size_t)wave * L;
   int32_t* ei = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(knn_smem) + (size_t)4 * L) + (size_t)wave * L;
+  uint32_t* ea = reinterpret_cast<uint32_t*>(reinterpret_cast<int32_t*>(reinterpret_cast<double*>(knn_smem) + (size_t)4 * L) + (size_t)4 * L) + (size_t)wave * L;
   const int64_t nq = p.nq_dev ? (int64_t)*p.nq_dev : p.Nq;
   const double eps = p.nprod > 0 ? (double)knn_eps(p.eps, p.nprod) : 0.0;
   for (int64_t qi = (int64_t)blockIdx.x * 4 + wave; qi < nq; qi += (int64_t)gridDim.x * 4) {
@@ -696,15 +699,56 @@ __global__ __launch_bounds__(256) void refine_kernel(Canon canon, const RefinePa
     float alast = -INFINITY;
     for (int s = lane; s < p.nslots; s += 64) alast = fmaxf(alast, p.sl_tau[qi * p.nslots + s]);
     alast = bgnn::group_max<64>(alast);
-    int ns = 0;
+    // (1) listed candidates above alast -> LDS (candidate, ordered approximate score)
+    int n1 = 0;
+    uint32_t amax = ORD_EMPTY;
     for (int e0 = 0; e0 < L; e0 += 64) {
       const int e = e0 + lane;
       const int32_t c = e < L ? p.sl_idx[qi * L + e] : -1;
-      const bool surv = c >= 0 && p.sl_score[qi * L + e] > alast;
+      const float a = e < L ? p.sl_score[qi * L + e] : -INFINITY;
+      const bool in = c >= 0 && a > alast;
+      const unsigned long long b = __ballot(in);
+      if (in) {
+        const int pos = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        ei[pos] = c;
+        ea[pos] = ord_f32(a);
+        amax = ord_f32(a) > amax ? ord_f32(a) : amax;
+      }
+      n1 += __popcll(b);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // (2) bracket the k-th best approximate score: count(> lo) >= k > count(> hi)
+    float T = alast;
+    if (n1 >= p.k) {
+      uint32_t lo = ord_f32(alast), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgnn_wave_max_u32(amax));
+      auto count_above = [&](uint32_t piv) {
+        int c = 0;
+        for (int e0 = 0; e0 < n1; e0 += 64) c += __popcll(__ballot(e0 + lane < n1 && ea[e0 + lane] > piv));
+        return c;
+      };
+      for (int it = 0; it < 32 && hi - lo > 64u; ++it) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const bool ge = count_above(mid) >= p.k;
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid;
+      }
+      const float ak = unord_f32(lo);                 // a lower bound of the k-th best approximate score
+      const float margin = p.nprod > 0 ? (float)(2.0 * eps) + 1e-7f : (float)(2.0 * (p.err_abs + p.err_rel * fabs((double)ak))) + 1e-7f;
+      T = fmaxf(alast, ak - margin);
+    }
+    // (3) survivors above T: exact canonical scores
+    const uint32_t To = ord_f32(T);
+    int ns = 0;
+    for (int e0 = 0; e0 < n1; e0 += 64) {
+      const int e = e0 + lane;
+      const bool surv = e < n1 && ea[e] > To;
+      const int32_t c = e < n1 ? ei[e] : -1;
       const unsigned long long b = __ballot(surv);
+      __builtin_amdgcn_wave_barrier();                // every lane has read ei[e] before the packed writes below reuse the array
       if (surv) {
         const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        ei[pos] = c;
+        ei[pos] = c;                                  // pos <= e: packing in place is safe chunk by chunk
         es[pos] = canon(q, c);
       }
       ns += __popcll(b);
@@ -733,8 +777,8 @@ __global__ __launch_bounds__(256) void refine_kernel(Canon canon, const RefinePa
       kmax = other > kmax ? other : kmax;
     }
     const bool have = ns >= p.k;
-    const double bound = p.nprod > 0 ? eps : p.err_abs + p.err_rel * fabs((double)alast);
-    const bool proven = have && ((alast == -INFINITY) || kmax > (double)alast + bound);
+    const double bound = p.nprod > 0 ? eps : p.err_abs + p.err_rel * fabs((double)T);
+    const bool proven = have && ((T == -INFINITY) || kmax > (double)T + bound);
     if (!proven && lane == 0) {
       const int slot = atomicAdd(p.fail_count, 1);
       p.fail_list[slot] = (int32_t)q;
@@ -963,7 +1007,7 @@ static int launch_refine(const Canon& canon, const RefineParams& rp, hipStream_t
   int64_t grid = (rp.Nq + 3) / 4;
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  const size_t sh = (size_t)4 * rp.L * (sizeof(double) + sizeof(int32_t));
+  const size_t sh = (size_t)4 * rp.L * (sizeof(double) + sizeof(int32_t) + sizeof(uint32_t));
   hipLaunchKernelGGL((refine_kernel<Canon>), dim3((unsigned)grid), dim3(256), sh, st, canon, rp);
   BGNN_LAUNCH_CHECK();
   return 0;
