@@ -888,7 +888,7 @@ __global__ void copy_counts_kernel(const int32_t* __restrict__ exhaustive, const
 // host side: geometry and workspace
 struct Geom { int cap, kp, tpi; };                  // shortlist geometry by k; MFMA tiles staged per barrier
 static Geom geom_fast(int k) { return k <= 20 ? Geom{62, 48, 2} : Geom{128, 112, 1}; }     // 62: leaves LDS for 2 x 64-row stages
-static Geom geom_precise(int k) { return k <= 20 ? Geom{64, 32, 1} : Geom{128, 96, 1}; }
+static Geom geom_precise(int k) { return k <= 20 ? Geom{64, 56, 1} : Geom{128, 120, 1}; }   // wide windows: only rows the fast pass could not prove come here
 static Geom geom_mlp(int k) { return k <= 24 ? Geom{64, 40, 1} : Geom{128, 112, 1}; }
 static int max_kp(int k) { return geom_fast(k).kp; }
 
@@ -988,7 +988,7 @@ static int pass1_dk(int nprod, int k, const P1Params& p, const Pass1Plan* plan, 
     if (qpb_out) { *qpb_out = pass1_waves<DK, NP, CAPV, TPI>() * QPW; return 0; }                      \
     return launch_pass1<DK, NP, CAPV, KPV, TPI>(p, plan, st);                                          \
   } while (0)
-  if (nprod == 3) { if (geom_precise(k).cap == 64) BGNN_P1(3, 64, 32, 1); else BGNN_P1(3, 128, 96, 1); }
+  if (nprod == 3) { if (geom_precise(k).cap == 64) BGNN_P1(3, 64, 56, 1); else BGNN_P1(3, 128, 120, 1); }
   if (nprod == 2) { if (geom_fast(k).cap == 62) BGNN_P1(2, 62, 48, 2); else BGNN_P1(2, 128, 112, 1); }
   if (geom_fast(k).cap == 62) BGNN_P1(1, 62, 48, 2); else BGNN_P1(1, 128, 112, 1);
 #undef BGNN_P1

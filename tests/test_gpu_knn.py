@@ -194,3 +194,36 @@ def test_v1_sage_encoders_from_twitter_ckpt(golden):
     zt = model.encode_target(Data(x=_t(f["x_tar"]), edge_index=_t(f["ei_tar"].astype(np.int64))))
     assert_close(zs.cpu().numpy(), f["z_src"], rtol=2e-5, atol_scale=2e-6, what="z_src")
     assert_close(zt.cpu().numpy(), f["z_tar"], rtol=2e-5, atol_scale=2e-6, what="z_tar")
+
+
+def test_cosine_topk_cascade_stages_are_exercised():
+    """The filter cascade stage by stage.  (a) collapsed embeddings (every candidate within ~1e-3 of every other one, like the
+    reference's trained twitter embeddings, SURVEY 7 hard part 1): hundreds of candidates lie inside the fast pass's 2-eps margin,
+    its 48-entry window overflows, the proof fails and the PRECISE pass (three products, eps ~ 6e-5, 56-entry window) resolves
+    most of the rows, the exhaustive stage the rest; (b) well separated data: no row leaves the fast stage; (c) duplicated
+    candidates tie exactly at the k boundary INSIDE the shortlist: resolved by the canonical rank (lower index), no further stage
+    (a whole candidate set of identical vectors does reach the exhaustive stage: test_cosine_topk_exact_ties_and_duplicates).
+    Indices bit-exact against the oracle in all three."""
+    from bridged_gnn_amd import ops, synth
+    rng = np.random.default_rng(42)
+    d, k = 128, 20
+    centre = rng.standard_normal(d)
+    ce = (centre + 2e-2 * rng.standard_normal((6000, d))).astype(np.float32)        # cosines all in [0.97, 1]
+    qe = (centre + 2e-2 * rng.standard_normal((300, d))).astype(np.float32)
+    q, c = OC.l2_normalize_rows(qe), OC.l2_normalize_rows(ce)
+    idx, val, nfb = ops.cosine_topk(_t(q), _t(c), k, apply_sigmoid=False)
+    rv, ri = OC.cosine_topk(q, c, k)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert int(nfb[1].item()) > 0, "the collapsed embeddings were expected to overflow the fast pass's margin window"
+    assert int(nfb[0].item()) < int(nfb[1].item()), "the precise pass should resolve part of the rows it is given"
+    # (b)
+    q2 = OC.l2_normalize_rows(synth.gaussian_embeddings(300, d, seed=8))
+    c2 = OC.l2_normalize_rows(synth.gaussian_embeddings(6000, d, seed=9))
+    idx2, _, nfb2 = ops.cosine_topk(_t(q2), _t(c2), k, apply_sigmoid=False)
+    assert np.array_equal(idx2.cpu().numpy(), OC.cosine_topk(q2, c2, k)[1])
+    assert int(nfb2[0].item()) == 0 and int(nfb2[1].item()) <= 1
+    # (c) the k-th and (k+1)-th candidates of every query are the same vector
+    c3 = np.concatenate([c2, c2[:3000]])
+    idx3, _, nfb3 = ops.cosine_topk(_t(q2), _t(c3), k, apply_sigmoid=False)
+    assert np.array_equal(idx3.cpu().numpy(), OC.cosine_topk(q2, c3, k)[1])
+    assert int(nfb3[0].item()) == 0
