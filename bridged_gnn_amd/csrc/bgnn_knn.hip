@@ -89,23 +89,24 @@ __device__ __forceinline__ uint32_t bgnn_wave_max_u32(uint32_t x) {
 // Invariant: every candidate that was ever refused or dropped has an approximate score <= tau (tau never decreases).
 template <int CAPV, int KPV>
 struct WaveTopK {
-  static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64;
+  static constexpr int CAP = CAPV, KP = KPV, EPL = (CAPV + 63) / 64, HC = CAPV / 2;
   static_assert(CAPV <= 128 && CAPV % 2 == 0, "one or two buffer entries per lane");
-  static_assert(KPV < CAPV, "slack between two compactions");
-  static constexpr size_t BYTES = 2 * sizeof(uint32_t) * QPW * CAPV + sizeof(int) * QPW + sizeof(float) * QPW;
+  static_assert(KPV < CAPV && (KPV + 1) / 2 < CAPV / 2, "slack between two compactions in both halves");
+  static constexpr size_t BYTES = 2 * sizeof(uint32_t) * QPW * CAPV + sizeof(int) * 2 * QPW + sizeof(float) * QPW;
   // the state is addressed as an OFFSET into the kernel's dynamic LDS (not as generic pointers): the accessors below
   // keep the address space visible to the compiler across the noinline helpers (ds_* instead of flat_* accesses)
   unsigned base;                         // byte offset of this wave's state in knn_smem
   int k;                                 // wanted neighbours
   float margin_abs, margin_rel;          // margin(a) = margin_abs + margin_rel * |a|
-  __device__ __forceinline__ uint32_t* skey() const { return reinterpret_cast<uint32_t*>(knn_smem + base); }            // [QPW][CAP] score bits
-  __device__ __forceinline__ uint32_t* sidx() const { return skey() + QPW * CAP; }                                      // [QPW][CAP] candidate
-  __device__ __forceinline__ int* cnt() const { return reinterpret_cast<int*>(sidx() + QPW * CAP); }                    // [QPW]
-  __device__ __forceinline__ float* tau() const { return reinterpret_cast<float*>(cnt() + QPW); }                       // [QPW]
+  __device__ __forceinline__ uint32_t* skey() const { return reinterpret_cast<uint32_t*>(knn_smem + base); }            // [QPW][2][HC] score bits
+  __device__ __forceinline__ uint32_t* sidx() const { return skey() + QPW * CAP; }                                      // [QPW][2][HC] candidate
+  __device__ __forceinline__ int* cnt() const { return reinterpret_cast<int*>(sidx() + QPW * CAP); }                    // [2][QPW]: mailbox, index = lane
+  __device__ __forceinline__ float* tau() const { return reinterpret_cast<float*>(cnt() + 2 * QPW); }                   // [QPW]
 
   __device__ __forceinline__ void carve(unsigned byte_offset) { base = byte_offset; }
   __device__ __forceinline__ void init(int lane, float tau0) {          // tau0: the lane's query (lane & 31)
-    if (lane < QPW) { cnt()[lane] = 0; tau()[lane] = tau0; }
+    cnt()[lane] = 0;
+    if (lane < QPW) tau()[lane] = tau0;
   }
   // number of buffer entries of this wave's lanes (EPL per lane) whose ordered score exceeds the scalar pivot
   __device__ __forceinline__ static int count_above(const uint32_t (&s)[EPL], uint32_t pivot) {
@@ -114,17 +115,22 @@ struct WaveTopK {
     for (int e = 0; e < EPL; ++e) c += __popcll(__ballot(s[e] > pivot));
     return c;
   }
-  // Compaction of query q's buffer (whole wave, uniform q).
+  // Compaction of query q's buffer (whole wave, uniform q); the halves' fill counts are in the mailbox cnt[h*32 + q].
   __device__ __forceinline__ void compact(int q, int lane) {
-    const int n = min(cnt()[q], CAP);
+    const int cA = min(cnt()[q], HC), cB = min(cnt()[QPW + q], HC);
+    const int n = cA + cB;
     const float tau_old = tau()[q];
     uint32_t s[EPL], x[EPL];
     uint32_t smax = ORD_EMPTY;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      const int i = lane + 64 * e;
-      s[e] = i < n ? ord_f32(__uint_as_float(skey()[q * CAP + i])) : ORD_EMPTY;      // empty slots carry 0 < ord(-inf)
-      x[e] = sidx()[q * CAP + i];
+      // element (e, lane) -> (half, slot): one entry per lane walks half 0 then half 1; two entries per lane = the two halves
+      const int half = EPL == 1 ? (lane >= HC ? 1 : 0) : e;
+      const int slot = EPL == 1 ? lane - half * HC : lane;
+      const bool valid = slot < (half ? cB : cA) && (EPL == 2 || lane < CAP);
+      const int src = q * CAP + half * HC + slot;
+      s[e] = valid ? ord_f32(__uint_as_float(skey()[src])) : ORD_EMPTY;              // empty slots carry 0 < ord(-inf)
+      x[e] = valid ? sidx()[src] : 0u;
       smax = s[e] > smax ? s[e] : smax;
     }
     // bracket the `want`-th best: count(s > lo) >= want > count(s > hi)
@@ -156,27 +162,30 @@ struct WaveTopK {
         lo = gt ? mid : lo;
         hi = gt ? hi : mid;
       }
-      lo = hi;
-      tmo = lo;
+      tmo = hi;
       tm = unord_f32(tmo);
       cm = count_above(s, tmo);
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // every read of the old layout is done before the packed stores
     int before = 0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const bool kp = s[e] > tmo;
       const unsigned long long b = __ballot(kp);
-      if (kp) {
+      if (kp) {                                     // packed position p -> half p & 1, slot p >> 1: both halves keep their slack
         const int pos = before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        skey()[q * CAP + pos] = __float_as_uint(unord_f32(s[e]));
-        sidx()[q * CAP + pos] = x[e];
+        const int dst = q * CAP + (pos & 1) * HC + (pos >> 1);
+        skey()[dst] = __float_as_uint(unord_f32(s[e]));
+        sidx()[dst] = x[e];
       }
       before += __popcll(b);
     }
-    if (lane == 0) { cnt()[q] = cm; tau()[q] = tm; }
+    if (lane == 0) { cnt()[q] = (cm + 1) >> 1; cnt()[QPW + q] = cm >> 1; tau()[q] = tm; }
   }
 };
 
+// compaction of the queries in qmask; the caller has published every lane's fill count to the mailbox (cnt[lane]) and
+// reloads count and threshold afterwards
 template <class TK>
 __device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
   while (qmask) {
@@ -184,40 +193,40 @@ __device__ __noinline__ void compact_rows(TK tk, unsigned int qmask, int lane) {
     qmask &= qmask - 1;
     tk.compact(qq, lane);
   }
-  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the new cnt / tau are visible to the wave's next LDS reads
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the new counts / tau are visible to the wave's next LDS reads
 }
 
-// Lanes in `pend` hold an arrival (ordered score so, candidate cand, query q) that found its buffer full: compact the
-// buffers involved and insert what still beats the raised thresholds.  Rare path (a buffer fills every ~30 arrivals).
+// Lanes in `pend` hold an arrival (score bits so, candidate cand) that found their half of the query's buffer full:
+// compact the buffers involved and insert what still beats the raised thresholds.  Rare path.  -> the lane's new count.
 template <class TK>
-__device__ __noinline__ void insert_overflow(TK tk, bool pend, uint32_t so, uint32_t cand, int q, int lane) {
-  constexpr int CAP = TK::CAP;
-  for (int guard = 0; guard < 64; ++guard) {
-    unsigned long long over = __ballot(pend);
-    if (!over) break;
-    unsigned int qmask = 0;                         // distinct queries among the pending lanes
-    while (over) {
-      const int lead = __ffsll((long long)over) - 1;
-      const int qsel = __builtin_amdgcn_readlane(q, lead);
-      qmask |= 1u << qsel;
-      over &= ~__ballot(pend && q == qsel);
-    }
-    compact_rows(tk, qmask, lane);
-    pend = pend && __uint_as_float(so) > tk.tau()[q];
-    if (pend) {
-      const int slot = atomicAdd(&tk.cnt()[q], 1);
-      if (slot < CAP) { tk.skey()[q * CAP + slot] = so; tk.sidx()[q * CAP + slot] = cand; pend = false; }
-    }
+__device__ __noinline__ int insert_overflow(TK tk, bool pend, uint32_t so, uint32_t cand, int mycnt, int lane) {
+  constexpr int CAP = TK::CAP, HC = TK::HC;
+  const int q = lane & 31, h = lane >> 5;
+  tk.cnt()[lane] = mycnt;                           // publish the fill counts
+  unsigned long long over = __ballot(pend);
+  unsigned int qmask = 0;                           // distinct queries among the pending lanes
+  while (over) {
+    const int lead = __ffsll((long long)over) - 1;
+    qmask |= 1u << (lead & 31);
+    over &= over - 1;
   }
+  compact_rows(tk, qmask, lane);
+  mycnt = tk.cnt()[lane];
+  if (pend && __uint_as_float(so) > tk.tau()[q]) {  // after a compaction every half holds at most (KP + 1) / 2 < HC entries
+    tk.skey()[q * CAP + h * HC + mycnt] = so;
+    tk.sidx()[q * CAP + h * HC + mycnt] = cand;
+    ++mycnt;
+  }
+  return mycnt;
 }
 
-// Offer the 16 scores a lane holds (one query q = lane & 31, candidates cbase + cand(r, h)).  One ballot per accumulator
-// register: a register nobody beats the threshold with costs a compare and a scalar branch; an arrival costs one
-// returning LDS atomic and two stores for all lanes of that register at once -- no per-lane bit masks, no runtime
-// register select, no queue.
+// Offer the 16 scores a lane holds (one query q = lane & 31, candidates cbase + cand(r, h)).  A register nobody beats the
+// threshold with costs a compare and a scalar branch.  An arrival goes into the lane's OWN half of the query's buffer
+// (lanes (q, 0) and (q, 1) each own HC slots and keep their fill count in a register): two LDS stores, no atomic and no
+// wait for its return (the shared-count form spent ~1000 cycles per 64 candidates waiting for ds_add_rtn).
 template <class TK>
-__device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int cand_lo, int lane, float& tau) {
-  constexpr int CAP = TK::CAP;
+__device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_t Nc, int cand_lo, int lane, float& tau, int& mycnt) {
+  constexpr int CAP = TK::CAP, HC = TK::HC;
   const int q = lane & 31, h = lane >> 5;
   if (cbase + MT > Nc) {                            // last (partial) tile only: mask candidates >= Nc
 #pragma unroll
@@ -229,46 +238,55 @@ __device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_
   for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
   mx = fmaxf(mx, acc[15]);
   if (!__any(mx > tau)) return;
-  int* const my_cnt = &tk.cnt()[q];
-  uint32_t* const my_row = tk.skey() + q * CAP;
+  uint32_t* const my_half = tk.skey() + q * CAP + h * HC;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const bool hit = acc[r] > tau;
     if (__any(hit)) {                               // wave-uniform
       const uint32_t so = __float_as_uint(acc[r]);    // raw bits; the ordered form is made where entries are compared
       const uint32_t cand = (uint32_t)(cand_lo + cbase + (r & 3) + 8 * (r >> 2) + 4 * h);
-      bool pend = hit;
-      if (hit) {
-        const int slot = atomicAdd(my_cnt, 1);
-        if (slot < CAP) { my_row[slot] = so; my_row[QPW * CAP + slot] = cand; pend = false; }
-      }
-      if (__any(pend)) {                            // a buffer is full
-        insert_overflow(tk, pend, so, cand, q, lane);
+      const bool fits = hit && mycnt < HC;
+      if (fits) { my_half[mycnt] = so; my_half[QPW * CAP + mycnt] = cand; ++mycnt; }
+      if (__any(hit && !fits)) {                    // a half is full
+        mycnt = insert_overflow(tk, hit && !fits, so, cand, mycnt, lane);
         tau = tk.tau()[q];
       }
     }
   }
 }
 
+// scheduled compaction of the fuller buffers (see the pass-1 kernel): publish the counts, compact, reload
+template <class TK>
+__device__ __forceinline__ void compact_fullish(TK& tk, int lane, float& tau, int& mycnt, int free_slots) {
+  tk.cnt()[lane] = mycnt;
+  const int tot = mycnt + __shfl_xor(mycnt, 32);
+  const unsigned long long fullish = __ballot(lane < QPW && tot > TK::CAP - free_slots);
+  compact_rows(tk, (unsigned int)fullish, lane);
+  mycnt = tk.cnt()[lane];
+  tau = tk.tau()[lane & 31];
+}
+
 // final: every buffer trimmed to its threshold, then the (score, candidate) lists and the thresholds go to the workspace
 template <class TK>
-__device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int64_t q0, int64_t nq, float* __restrict__ sl_score,
+__device__ __forceinline__ void emit_shortlists(TK& tk, int lane, int mycnt, int64_t q0, int64_t nq, float* __restrict__ sl_score,
                                                 int32_t* __restrict__ sl_idx, float* __restrict__ sl_tau, int slot, int nslots,
                                                 uint32_t cand_lo = 0) {
-  constexpr int CAP = TK::CAP, KP = TK::KP, EPL = TK::EPL;
+  constexpr int CAP = TK::CAP, KP = TK::KP, EPL = TK::EPL, HC = TK::HC;
+  tk.cnt()[lane] = mycnt;
   compact_rows(tk, 0xFFFFFFFFu, lane);
   for (int q = 0; q < QPW; ++q) {
     const int64_t gq = q0 + q;
     if (gq < nq) {
-      const int n = tk.cnt()[q];
+      const int n = tk.cnt()[q] + tk.cnt()[QPW + q];          // packed: entry p sits in half p & 1, slot p >> 1
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int pos = lane + 64 * e;
         if (pos < KP) {
           const int64_t o = (gq * nslots + slot) * KP + pos;
-          const bool own = pos < n && tk.sidx()[q * CAP + pos] >= cand_lo;        // seeds of the head pass stay in its slots
-          sl_score[o] = own ? __uint_as_float(tk.skey()[q * CAP + pos]) : -INFINITY;
-          sl_idx[o] = own ? (int32_t)tk.sidx()[q * CAP + pos] : -1;
+          const int src = q * CAP + (pos & 1) * HC + (pos >> 1);
+          const bool own = pos < n && tk.sidx()[src] >= cand_lo;                  // seeds of the head pass stay in its slots
+          sl_score[o] = own ? __uint_as_float(tk.skey()[src]) : -INFINITY;
+          sl_idx[o] = own ? (int32_t)tk.sidx()[src] : -1;
         }
       }
       if (lane == 0) sl_tau[gq * nslots + slot] = tk.tau()[q];
@@ -456,6 +474,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
     float tau = -INFINITY;
     if (p.tau_init && q0 + fr < nq) tau = p.tau_init[q0 + fr];
     tk.init(lane, tau);
+    int mycnt = 0;                                  // fill count of this lane's half of its query's buffer
     if (p.tau_init) {
       // Seed the buffers with the head pass's entries above the threshold: the segment then CONTINUES the head's stream
       // (its k-th best can only rise from there) instead of re-learning the threshold from its own candidates alone.
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
         const float t0 = p.tau_init[gq];
         int have = 0;
         const int ne = p.carry_slots * KPV;
-        for (int e0 = 0; e0 < ne && have < CAPV; e0 += 64) {
+        for (int e0 = 0; e0 < ne && have < KPV; e0 += 64) {
           const int e = e0 + lane;
           const int64_t o = gq * p.nslots * KPV + e;            // head slots are the first ones of the query's row
           const int32_t c = e < ne ? p.sl_idx[o] : -1;
@@ -474,11 +493,18 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
           const bool kp = c >= 0 && sc > t0;
           const unsigned long long b = __ballot(kp);
           const int pos = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-          if (kp && pos < CAPV) { tk.skey()[qq * CAPV + pos] = __float_as_uint(sc); tk.sidx()[qq * CAPV + pos] = (uint32_t)c; }
+          if (kp && pos < KPV) {                      // packed position p -> half p & 1, slot p >> 1
+            const int dst = qq * CAPV + (pos & 1) * TK::HC + (pos >> 1);
+            tk.skey()[dst] = __float_as_uint(sc);
+            tk.sidx()[dst] = (uint32_t)c;
+          }
           have += __popcll(b);
         }
-        if (lane == 0) tk.cnt()[qq] = have < CAPV ? have : CAPV;
+        have = have < KPV ? have : KPV;
+        if (lane == 0) { tk.cnt()[qq] = (have + 1) >> 1; tk.cnt()[QPW + qq] = have >> 1; }
       }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      mycnt = tk.cnt()[lane];
     }
     __syncthreads();                                // the previous segment's last tile has been read by every wave
     gload(ct0);
@@ -538,12 +564,10 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
       if (i > 0) {                                      // the upkeep of unit i-1
 #pragma unroll
         for (int u = 0; u < TPI; ++u)
-          offer_tile(tk, accP[u], (int)(ct0 + i - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau);
+          offer_tile(tk, accP[u], (int)(ct0 + i - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau, mycnt);
         if (p.known_tiles + i >= next_c) {
           // only the buffers that could fill before the next scheduled compaction (the others keep their slack)
-          const unsigned long long fullish = __ballot(lane < QPW && tk.cnt()[lane & 31] > CAPV - KNN_SCHED_FREE);
-          compact_rows(tk, (unsigned int)fullish, lane);
-          tau = tk.tau()[lane & 31];
+          compact_fullish(tk, lane, tau, mycnt, KNN_SCHED_FREE);
           next_c += (next_c * KNN_SCHED_NUM >> 3) > 0 ? (next_c * KNN_SCHED_NUM >> 3) : 1;
         }
       }
@@ -557,8 +581,8 @@ __global__ __launch_bounds__(64 * NW) void cosine_pass1_kernel(const P1Params p)
     }
 #pragma unroll
     for (int u = 0; u < TPI; ++u)
-      offer_tile(tk, accP[u], (int)(ct1 - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau);
-    emit_shortlists(tk, lane, q0, nq, p.sl_score, p.sl_idx, p.sl_tau, slot, p.nslots, (uint32_t)p.cand_lo);
+      offer_tile(tk, accP[u], (int)(ct1 - 1) * CT + u * MT, p.Nc, (int)p.cand_lo, lane, tau, mycnt);
+    emit_shortlists(tk, lane, mycnt, q0, nq, p.sl_score, p.sl_idx, p.sl_tau, slot, p.nslots, (uint32_t)p.cand_lo);
     t += ct1 - ct0;
   }
 }
@@ -596,6 +620,7 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
       bqv[h4] = gq < Nq ? *reinterpret_cast<const float4*>(B + gq * H + h4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float tau = -INFINITY;
+  int mycnt = 0;
   const int fh = lane >> 5;
   const float4* sc4 = reinterpret_cast<const float4*>(coefs);
   const float4* sh4 = reinterpret_cast<const float4*>(coefs + H);
@@ -625,9 +650,9 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
         acc[r] = fmaf(w.w, fmaxf(fmaf(sc.w, a.w + bb.w, sh.w), 0.f), acc[r]);
       }
     }
-    offer_tile(tk, acc, (int)cb, Nc, 0, lane, tau);
+    offer_tile(tk, acc, (int)cb, Nc, 0, lane, tau, mycnt);
   }
-  emit_shortlists(tk, lane, q0, Nq, sl_score, sl_idx, sl_tau, 0, 1);
+  emit_shortlists(tk, lane, mycnt, q0, Nq, sl_score, sl_idx, sl_tau, 0, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -960,7 +985,7 @@ static int device_cus() {
 template <int DK, int NPROD, int CAPV, int TPI>
 constexpr int pass1_waves() {
   constexpr size_t stage = (size_t)2 * (NPROD == 3 ? 2 : 1) * MT * TPI * DK * 8 * 2;
-  constexpr size_t per_wave = sizeof(u64) * QPW * CAPV + 2 * 4 * QPW;
+  constexpr size_t per_wave = sizeof(u64) * QPW * CAPV + 3 * 4 * QPW;
   return (stage + 8 * per_wave <= (size_t)LDS_BYTES) ? 8 : (stage + 4 * per_wave <= (size_t)LDS_BYTES) ? 4 : (stage + 2 * per_wave <= (size_t)LDS_BYTES) ? 2 : 1;
 }
 
