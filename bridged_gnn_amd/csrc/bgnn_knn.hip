@@ -259,8 +259,9 @@ __device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_
 template <class TK>
 __device__ __forceinline__ void compact_fullish(TK& tk, int lane, float& tau, int& mycnt, int free_slots) {
   tk.cnt()[lane] = mycnt;
-  const int tot = mycnt + __shfl_xor(mycnt, 32);
-  const unsigned long long fullish = __ballot(lane < QPW && tot > TK::CAP - free_slots);
+  const int other = __shfl_xor(mycnt, 32);
+  const int hi = mycnt > other ? mycnt : other;       // a query overflows when ONE of its halves is full
+  const unsigned long long fullish = __ballot(lane < QPW && (mycnt + other > TK::CAP - free_slots || hi > TK::HC - free_slots / 3));
   compact_rows(tk, (unsigned int)fullish, lane);
   mycnt = tk.cnt()[lane];
   tau = tk.tau()[lane & 31];
