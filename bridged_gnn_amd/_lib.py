@@ -33,6 +33,8 @@ SIGNATURES = {
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
     "bgnn_gram_f32": (_INT, [_P, _I64, _I32, _P, _I64, _I32, _I64, _P, _P, C.c_size_t, _P]),
     "bgnn_transform_bwd_prep_f32": (_INT, [_P, _I64, _I64, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
+    "bgnn_bn_relu_dropout_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _F32, _INT, _F32, C.c_uint64, _F32, _P, _P, _P, _I64, _P, _P]),
+    "bgnn_bn_relu_dropout_bwd_f32": (_INT, [_P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _F32, _INT, _F32, C.c_uint64, _P, _I64, _P, _P]),
     "bgnn_rowdot_f32": (_INT, [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "bgnn_linear_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _I64, _P]),
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
@@ -68,7 +70,7 @@ def source_hash():
 
 # keep in step with HASHED in csrc/Makefile
 _HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
-                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_common.h", os.path.join("..", "..", "include", "bgnn.h"))
+                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", os.path.join("..", "..", "include", "bgnn.h"))
 
 
 def _sidecar_hash():

@@ -134,6 +134,50 @@ def _pad_cols4(t):
     return t.contiguous() if pad == 0 else F.pad(t, (0, pad)).contiguous()
 
 
+class _BnReluDropFn(torch.autograd.Function):
+    """Training-mode `BatchNorm1d` -> `F.relu` -> `F.dropout` (KTGNN.py:420-430; clf_transformer's BN + ReLU with p = 0) as
+    two streaming HIP launches forward and two backward (torch: eight launches and three saved [N, D] intermediates).
+    Only x is kept for the backward: the ReLU state is re-derived from it, the dropout mask from (seed, element index)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu, p_drop):
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0   # host generator: no sync
+        track = bn.track_running_stats and bn.running_mean is not None
+        mom = 0.0
+        if track:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            mom = bn.momentum              # (momentum None = cumulative average: left to torch, see bn_relu_dropout_train)
+        y, stats = ops.bn_relu_dropout(x, weight.detach() if weight is not None else None,
+                                       bias.detach() if bias is not None else None, bn.eps, relu, p_drop, seed, mom,
+                                       bn.running_mean if track else None, bn.running_var if track else None)
+        ctx.save_for_backward(x, weight, bias, stats)
+        ctx.cfg = (bn.eps, relu, p_drop, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, stats = ctx.saved_tensors
+        eps, relu, p_drop, seed = ctx.cfg
+        gy = gy if (gy.stride(1) == 1 and gy.stride(0) % 4 == 0 and gy.data_ptr() % 16 == 0) else gy.contiguous()
+        gx, gsum = ops.bn_relu_dropout_bwd(x, gy, stats, weight.detach() if weight is not None else None,
+                                           bias.detach() if bias is not None else None, eps, relu, p_drop, seed)
+        D = x.shape[1]
+        gs = gsum.float()
+        return (gx if ctx.needs_input_grad[0] else None, gs[D:] if weight is not None else None,
+                gs[:D] if bias is not None else None, None, None, None)
+
+
+def bn_relu_dropout_train(x, bn, relu, p_drop):
+    """fused training-mode BN -> ReLU -> dropout when the shape is inside the kernel's envelope, the torch ops otherwise"""
+    if (bn.training and ops.bn_relu_dropout_supported(x) and x.shape[0] > 1
+            and (bn.momentum is not None or not bn.track_running_stats)):
+        return _BnReluDropFn.apply(x, bn.weight, bn.bias, bn, relu, float(p_drop))
+    x = bn(x)
+    x = F.relu(x) if relu else x
+    return F.dropout(x, p=p_drop, training=True) if p_drop > 0 else x
+
+
 class _AggregateFn(torch.autograd.Function):
     """out = fused attention aggregation (KTGNN.py:292-305); backward = HIP kernel (atomics on the
     scattered source-side sums)."""
@@ -465,10 +509,13 @@ class KTGNN_no_complement(nn.Module):
                 x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
             else:
                 x = conv(x, None, central_mask=central_mask, csr=csr, sums=sums_in)
-                if self.use_bn:
-                    x = self.bns[ind](x)
-                x = F.relu(x)
-                x = F.dropout(x, p=self.dropout, training=self.training)
+                if self.use_bn and self.training and torch.is_grad_enabled():
+                    x = bn_relu_dropout_train(x, self.bns[ind], True, self.dropout)
+                else:
+                    if self.use_bn:
+                        x = self.bns[ind](x)
+                    x = F.relu(x)
+                    x = F.dropout(x, p=self.dropout, training=self.training)
         self._arena = arena
         return (x, sums) if want_sums else x
 
@@ -582,7 +629,11 @@ class KTGNN_no_complement(nn.Module):
             # the folded / raw-kernel eval form has no autograd: with grad enabled (fine-tuning with frozen BN, input
             # attribution) the module itself runs -- eval-mode BatchNorm is autograd-safe
             needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.clf_transformer.parameters()))
-            xt = self.clf_transformer(x) if (self.training or needs_grad) else self._transformer_eval(x)
+            if self.training and torch.is_grad_enabled():
+                l0, bn, _, l3 = self.clf_transformer
+                xt = l3(bn_relu_dropout_train(l0(x), bn, True, 0.0))
+            else:
+                xt = self.clf_transformer(x) if (self.training or needs_grad) else self._transformer_eval(x)
             logits_hat = self.clf_target(xt.contiguous(), None, central_mask=central_mask, csr=csr)       # :433
         else:
             # the three classifier convs share the graph: their six narrow tables are interleaved per node

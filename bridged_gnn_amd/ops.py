@@ -202,6 +202,40 @@ def gram(A, B):
     return out
 
 
+def bn_relu_dropout_supported(x):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0
+            and 4 <= x.shape[1] <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def bn_relu_dropout(x, gamma, beta, eps, relu, p_drop, seed, momentum=0.0, running_mean=None, running_var=None):
+    """Training-mode BatchNorm1d -> ReLU -> dropout (KTGNN.py:420-430) -> (y, stats); `stats` (fp64 column sums of x | x^2)
+    is what the backward needs besides x."""
+    N, D = x.shape
+    y = torch.empty(N, D, dtype=torch.float32, device=x.device)
+    stats = torch.empty(2 * D, dtype=torch.float64, device=x.device)
+    rc = L.lib().bgnn_bn_relu_dropout_f32(L.ptr_rows(x), N, D, x.stride(0), L.ptr(gamma) if gamma is not None else None,
+                                          L.ptr(beta) if beta is not None else None, float(eps), int(bool(relu)), float(p_drop),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, float(momentum),
+                                          L.ptr(running_mean) if running_mean is not None else None,
+                                          L.ptr(running_var) if running_var is not None else None,
+                                          L.ptr(y), D, L.ptr(stats), L.stream())
+    L.check(rc, "bgnn_bn_relu_dropout_f32")
+    return y, stats
+
+
+def bn_relu_dropout_bwd(x, grad_y, stats, gamma, beta, eps, relu, p_drop, seed):
+    """-> (dL/dx [N,D], gsum fp64 [2*D] = dL/dbeta | dL/dgamma)."""
+    N, D = x.shape
+    gx = torch.empty(N, D, dtype=torch.float32, device=x.device)
+    gsum = torch.empty(2 * D, dtype=torch.float64, device=x.device)
+    rc = L.lib().bgnn_bn_relu_dropout_bwd_f32(L.ptr_rows(x), L.ptr_rows(grad_y), N, D, x.stride(0), grad_y.stride(0), L.ptr(stats),
+                                              L.ptr(gamma) if gamma is not None else None, L.ptr(beta) if beta is not None else None,
+                                              float(eps), int(bool(relu)), float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              L.ptr(gx), D, L.ptr(gsum), L.stream())
+    L.check(rc, "bgnn_bn_relu_dropout_bwd_f32")
+    return gx, gsum
+
+
 def rowdot(X, V):
     """X [N,d] (unit column stride, 16-B aligned rows) times up to four vectors V [nv,d] -> [N,nv] in one pass over X."""
     N, d = X.shape

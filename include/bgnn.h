@@ -117,6 +117,23 @@ int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, const uint8_t*
 size_t bgnn_gram_workspace_bytes(int32_t p, int32_t q);
 int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float* B, int64_t ldb, int32_t q, int64_t N,
                   float* out /*[p][q]*/, void* ws, size_t ws_bytes, void* stream);
+/* Training-mode BatchNorm1d -> ReLU -> dropout over node rows (models/KTGNN.py:420-430: `self.bns[ind](x)`, `F.relu`,
+ *   `F.dropout(x, p=self.dropout, training=self.training)`; :364-367 clf_transformer's BatchNorm1d + ReLU with p = 0) in two
+ *   streaming launches.  x [N, D] (D % 4 == 0, D <= 1024), batch statistics over the N rows in fp64 (`stats` [2*D]: column sums
+ *   of x | x^2, written here and kept for the backward); y = keep(seed, element) ? max(gamma*(x-mean)/sqrt(var+eps)+beta, 0) / (1-p) : 0.
+ *   The dropout mask is a counter-based hash of (seed, element index) with 16 bits per element (p is rounded to 1/65536) -- the
+ *   same Bernoulli(1-p) law as torch's Philox stream, not the same bits.  running_mean / running_var (both or neither) get torch's
+ *   momentum update with the unbiased variance.
+ * bgnn_bn_relu_dropout_bwd_f32: dL/dx from dL/dy; the ReLU state is re-derived from x and the mask from (seed, index); `gsum`
+ *   [2*D] (fp64, written here) returns sum g' = dL/dbeta and sum g'.xhat = dL/dgamma (g' = dL/d(BN output)). */
+int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, int64_t ldx, const float* gamma_opt,
+                             const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed,
+                             float momentum, float* running_mean_opt, float* running_var_opt,
+                             float* y, int64_t ldy, double* stats, void* stream);
+int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y, int64_t N, int32_t D, int64_t ldx, int64_t ldg,
+                                 const double* stats, const float* gamma_opt, const float* beta_opt, float eps,
+                                 int relu, float p_drop, uint64_t seed, float* grad_x, int64_t ldgx,
+                                 double* gsum, void* stream);
 /* bgnn_transform_bwd_prep_f32: row-local part of the transform's hand-derived backward (KTGNN.py:275-284 under autograd) in
  *   one stream over x and the two incoming gradient tables: gate values (tanh of x.gx[g] + gconst[g]), the gates'
  *   adjoints G.(W delta) (wd [2][2D]: row 0 = -(W_t delta) in columns 0..D-1, row 1 = W_s delta in columns D..2D-1), and

@@ -190,3 +190,50 @@ def test_transform_bwd_prep_matches_torch_formula(din, D, n):
     assert torch.equal(Gall[:, :2 * D].double(), cat)
     assert torch.allclose(Gall.double(), want, rtol=1e-5, atol=1e-5 * float(dc.abs().max()))
     assert torch.allclose(side.double(), want_side, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,d,relu,p", [(5000, 128, True, 0.0), (3001, 64, True, 0.5), (777, 100, False, 0.25), (4097, 8, True, 0.0)])
+def test_fused_bn_relu_dropout_matches_torch_formula(n, d, relu, p):
+    """bgnn_bn_relu_dropout_f32 / _bwd (KTGNN.py:420-430 in train mode) vs the fp64 torch formula with the SAME mask (read back
+    from the kernel's output: y == 0 where dropped) -- forward, dL/dx, dL/dgamma, dL/dbeta and the running buffers."""
+    from bridged_gnn_amd.ktgnn import bn_relu_dropout_train
+    rng = np.random.default_rng(n + d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.5, 3.0, d) + rng.uniform(-2, 2, d)).astype(np.float32)
+    w = rng.standard_normal((n, d)).astype(np.float32)
+    torch.manual_seed(n)
+    bn = torch.nn.BatchNorm1d(d).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    bn.train()
+    xg = _t(x).requires_grad_(True)
+    y = bn_relu_dropout_train(xg, bn, relu, p)
+    assert type(y.grad_fn).__name__ == "_BnReluDropFnBackward", "the fused path must be the one that runs"
+    (y * _t(w)).sum().backward()
+    # fp64 reference with the kernel's own mask
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    g = bn.weight.detach().cpu().double().requires_grad_(True)
+    b = bn.bias.detach().cpu().double().requires_grad_(True)
+    mean, var = xo.mean(0), xo.var(0, unbiased=False)
+    z = (xo - mean) / torch.sqrt(var + bn.eps) * g + b
+    z = torch.relu(z) if relu else z
+    yc = y.detach().cpu().double()
+    if p > 0:
+        thr = round(p * 65536)
+        live = z.detach().abs() > 1e-6
+        keep = (yc != 0) | ~live                      # dropped <=> output zero although the activation is not
+        frac = float(((yc != 0) & live).double().sum() / live.double().sum())
+        assert abs(frac - (1 - thr / 65536)) < 0.02, frac
+        z = torch.where(keep, z * (65536.0 / (65536 - thr)), torch.zeros_like(z))
+    (z * torch.from_numpy(w).double()).sum().backward()
+    assert _rel(yc, z.detach()) < 2e-6
+    assert _rel(xg.grad.cpu().double(), xo.grad) < 2e-5
+    assert _rel(bn.weight.grad.cpu().double(), g.grad) < 2e-5
+    assert _rel(bn.bias.grad.cpu().double(), b.grad) < 2e-5
+    rm = 0.1 * mean.detach()
+    rv = 0.9 + 0.1 * xo.detach().var(0, unbiased=True)
+    assert _rel(bn.running_mean.cpu().double(), rm) < 1e-6 and _rel(bn.running_var.cpu().double(), rv) < 1e-6
+    assert int(bn.num_batches_tracked) == 1
+    if p > 0:                                          # a second call draws a different mask
+        y2 = bn_relu_dropout_train(xg, bn, relu, p)
+        assert not torch.equal(y2 == 0, y == 0)
