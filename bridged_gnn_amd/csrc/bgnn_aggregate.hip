@@ -47,7 +47,8 @@ struct AggParams {
                      // pair is one virtual row of the kernel (ldh/ldo below are the strides of a VIRTUAL row)
   float* state_ms;   // [rows][2] running (max, sum) of a row whose edges are visited in two launches
   int mode;          // 0: one launch; 1: first part -> leave (m, s) in state_ms and the raw accumulator in out;
-                     // 2: second part -> resume from them, then normalise + epilogue
+                     // 2: second part -> resume from them, then normalise + epilogue; 3 (narrow heads kernel): one launch
+                     // that also leaves the finished rows' (m, s) in state_ms
   int64_t park_begin;  // mode 1: nodes below it have no second part and are finished (normalise + epilogue) right away
   int tq_chunk;      // tiles per queue claim
   int tq_interleave; // see agg_wide_kernel
@@ -657,6 +658,10 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
         } else {
           const float inv = 1.f / (s[h] + 1e-16f);
           float4 r = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+          if (p.mode == 3) {       // training: the softmax state of the finished row, for the heads backward
+            p.state_ms[2 * (i * HEADS + h)] = m[h];
+            p.state_ms[2 * (i * HEADS + h) + 1] = s[h];
+          }
           if (p.ep_relu == 2) {    // log_softmax over the head's D classes (KTGNN.py:435), row-local
             float mx = r.x;
             if (p.D > 1) mx = fmaxf(mx, r.y);
@@ -774,7 +779,8 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               double* colsum_opt, uint32_t* tile_queue_opt, void* stream) {
   if (colsum_opt && heads != 1) return BGNN_E_SHAPE;
   if (part == 1 && (park_begin < row_begin || park_begin > row_end)) return BGNN_E_SHAPE;
-  if (part < 0 || part > 2 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
+  if (part < 0 || part > 3 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
+  if (part == 3 && !((heads == 3 || heads == 2) && D <= 4 && ldh == 4 && ldo == 4)) return BGNN_E_SHAPE;
   if (heads < 1 || heads > 8 || (heads > 1 && (alpha_opt || ep_scale_opt))) return BGNN_E_SHAPE;
   if (ep_relu < 0 || ep_relu > 2) return BGNN_E_SHAPE;
   // ep_relu == 2: log_softmax epilogue instead of ReLU -- only the interleaved narrow-heads kernel has it

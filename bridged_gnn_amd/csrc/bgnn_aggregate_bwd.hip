@@ -486,6 +486,213 @@ static int launch_pull_narrow(const PullParams& p, hipStream_t st) {
   return 0;
 }
 
+// Interleaved narrow heads (KT-GNN's classifier stage under autograd: clf_base(x), clf_target(x), clf_target(T(x)) share the
+// graph): the pull form for HEADS convs in ONE walk per pass.  Tables / out / grad_out / dH are [N][HEADS][4] (48-byte rows
+// for three heads), the attention vectors [HEADS][D].  Nothing per edge is kept by the forward: alpha is rebuilt from the
+// finished rows' softmax state (m, s) that the forward leaves in `state_ms` (bgnn_adaptedconv_aggregate_f32, part 3), and with
+// `log_softmax` the incoming gradient is taken through the row-local log_softmax first: gr = g - exp(logp) * sum(g) -- then
+// t_i = gr . out_i can be formed from the log-probabilities themselves (sum(gr) = 0 cancels the unknown shift).
+// Record per edge (32 B): HEADS x {alpha, de} | bit 31 = domain of the destination, bits 4h..4h+3 = signs of h_j + h_i.
+struct HeadsBwdParams {
+  const float* h_t2s; const float* h_s2t;
+  const float* a_t2s; const float* a_s2t;
+  const int32_t* rowptr; const int32_t* col; const uint8_t* mask;
+  int64_t N; int32_t D; float slope;
+  const float* out; const float* state_ms; const float* gout; int log_softmax;
+  const int32_t* t_rowptr; const int32_t* t_eid; const int32_t* t_dst;
+  uint4* rec;            // [E'][2]
+  float* dstside;        // [N][HEADS][4]
+  float* grbuf;          // [N][HEADS][4]  gradient w.r.t. the aggregation output (after the log_softmax adjoint)
+  float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
+};
+
+__device__ __forceinline__ float4 mask_cols(float4 v, int D) {
+  if (D < 4) v.w = 0.f;
+  if (D < 3) v.z = 0.f;
+  if (D < 2) v.y = 0.f;
+  return v;
+}
+
+template <int HEADS, int EP>
+__global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p) {
+  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / EP, sub = lane % EP;
+  constexpr int64_t rs = HEADS * 4;
+  float4 accS[HEADS], accT[HEADS];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
+    const int64_t i = tile * RPB + wave * GPW + g;
+    const bool rvalid = i < p.N;
+    const int64_t ic = rvalid ? i : 0;
+    const bool dom_s = p.mask[ic] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    float4 a4[HEADS], hi[HEADS], gr[HEADS], accd[HEADS], accz[HEADS];
+    float ti[HEADS], mh[HEADS], inv[HEADS];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      a4[h].x = av[h * p.D];
+      a4[h].y = p.D > 1 ? av[h * p.D + 1] : 0.f;
+      a4[h].z = p.D > 2 ? av[h * p.D + 2] : 0.f;
+      a4[h].w = p.D > 3 ? av[h * p.D + 3] : 0.f;
+      hi[h] = *reinterpret_cast<const float4*>(H + ic * rs + 4 * h);
+      float4 gi = mask_cols(*reinterpret_cast<const float4*>(p.gout + ic * rs + 4 * h), p.D);
+      if (!rvalid) gi = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 oi = mask_cols(*reinterpret_cast<const float4*>(p.out + ic * rs + 4 * h), p.D);
+      if (p.log_softmax) {         // adjoint of the row-local log_softmax (pad columns stay 0)
+        const float sg = gi.x + gi.y + gi.z + gi.w;
+        gi.x -= expf(oi.x) * sg;
+        if (p.D > 1) gi.y -= expf(oi.y) * sg;
+        if (p.D > 2) gi.z -= expf(oi.z) * sg;
+        if (p.D > 3) gi.w -= expf(oi.w) * sg;
+      }
+      gr[h] = gi;
+      ti[h] = gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w;
+      mh[h] = p.state_ms[2 * (ic * HEADS + h)];
+      inv[h] = 1.f / (p.state_ms[2 * (ic * HEADS + h) + 1] + 1e-16f);
+      accd[h] = accz[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.grbuf + i * rs + 4 * h) = gi;
+    }
+    for (int32_t e = beg + sub; e < end; e += EP) {
+      const int32_t j = p.col[e];
+      float4 hj[HEADS];
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) hj[h] = *reinterpret_cast<const float4*>(H + (int64_t)j * rs + 4 * h);
+      uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      uint32_t bits = dom_s ? 0x80000000u : 0u;
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        const float zx = hj[h].x + hi[h].x, zy = hj[h].y + hi[h].y, zz = hj[h].z + hi[h].z, zw = hj[h].w + hi[h].w;
+        const bool px = zx > 0.f, py = zy > 0.f, pz = zz > 0.f, pw = zw > 0.f;
+        const float lx = px ? zx : zx * p.slope, ly = py ? zy : zy * p.slope, lz = pz ? zz : zz * p.slope, lw = pw ? zw : zw * p.slope;
+        float t = a4[h].x * lx;                       // the forward's logit, same operation order
+        t = fmaf(a4[h].y, ly, t); t = fmaf(a4[h].z, lz, t); t = fmaf(a4[h].w, lw, t);
+        const float al = __expf(t - mh[h]) * inv[h];
+        const float de = al * (gr[h].x * hj[h].x + gr[h].y * hj[h].y + gr[h].z * hj[h].z + gr[h].w * hj[h].w - ti[h]);
+        accd[h].x += de * a4[h].x * (px ? 1.f : p.slope); accd[h].y += de * a4[h].y * (py ? 1.f : p.slope);
+        accd[h].z += de * a4[h].z * (pz ? 1.f : p.slope); accd[h].w += de * a4[h].w * (pw ? 1.f : p.slope);
+        accz[h].x += de * lx; accz[h].y += de * ly; accz[h].z += de * lz; accz[h].w += de * lw;
+        w[2 * h] = __float_as_uint(al); w[2 * h + 1] = __float_as_uint(de);
+        bits |= ((px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (pw ? 8u : 0u)) << (4 * h);
+      }
+      w[7] = bits;
+      uint4* r = p.rec + (int64_t)e * 2;
+      r[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      r[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+      for (int off = 1; off < EP; off <<= 1) {
+        accd[h].x += __shfl_xor(accd[h].x, off); accd[h].y += __shfl_xor(accd[h].y, off);
+        accd[h].z += __shfl_xor(accd[h].z, off); accd[h].w += __shfl_xor(accd[h].w, off);
+      }
+      if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.dstside + i * rs + 4 * h) = accd[h];
+      if (rvalid) {
+        if (dom_s) { accS[h].x += accz[h].x; accS[h].y += accz[h].y; accS[h].z += accz[h].z; accS[h].w += accz[h].w; }
+        else       { accT[h].x += accz[h].x; accT[h].y += accz[h].y; accT[h].z += accz[h].z; accT[h].w += accz[h].w; }
+      }
+    }
+  }
+  // da: wave reduction, then one atomic per (wave, head, column, domain)
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+    float v[8] = {accS[h].x, accS[h].y, accS[h].z, accS[h].w, accT[h].x, accT[h].y, accT[h].z, accT[h].w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = bgnn::group_sum<64>(v[c]);
+      if (lane == 0 && (c & 3) < p.D) unsafeAtomicAdd(c < 4 ? &p.da_t2s[h * p.D + c] : &p.da_s2t[h * p.D + c - 4], v[c]);
+    }
+  }
+}
+
+template <int HEADS, int EP>
+__global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p) {
+  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / EP, sub = lane % EP;
+  constexpr int64_t rs = HEADS * 4;
+  float4 aS[HEADS], aT[HEADS];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+    aS[h].x = p.a_t2s[h * p.D]; aS[h].y = p.D > 1 ? p.a_t2s[h * p.D + 1] : 0.f;
+    aS[h].z = p.D > 2 ? p.a_t2s[h * p.D + 2] : 0.f; aS[h].w = p.D > 3 ? p.a_t2s[h * p.D + 3] : 0.f;
+    aT[h].x = p.a_s2t[h * p.D]; aT[h].y = p.D > 1 ? p.a_s2t[h * p.D + 1] : 0.f;
+    aT[h].z = p.D > 2 ? p.a_s2t[h * p.D + 2] : 0.f; aT[h].w = p.D > 3 ? p.a_s2t[h * p.D + 3] : 0.f;
+  }
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
+    const int64_t j = tile * RPB + wave * GPW + g;
+    const bool rvalid = j < p.N;
+    const int64_t jc = rvalid ? j : 0;
+    const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
+    float4 accS[HEADS], accT[HEADS];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int32_t k = beg + sub; k < end; k += EP) {
+      const int32_t e = p.t_eid[k], i = p.t_dst[k];
+      const uint4 r0 = p.rec[(int64_t)e * 2], r1 = p.rec[(int64_t)e * 2 + 1];
+      const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      const bool ds = (w[7] & 0x80000000u) != 0u;
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        const float4 g4 = *reinterpret_cast<const float4*>(p.grbuf + (int64_t)i * rs + 4 * h);
+        const float al = __uint_as_float(w[2 * h]), de = __uint_as_float(w[2 * h + 1]);
+        const uint32_t b = w[7] >> (4 * h);
+        const float4 a4 = ds ? aS[h] : aT[h];
+        float4 v;
+        v.x = fmaf(al, g4.x, de * a4.x * ((b & 1u) ? 1.f : p.slope));
+        v.y = fmaf(al, g4.y, de * a4.y * ((b & 2u) ? 1.f : p.slope));
+        v.z = fmaf(al, g4.z, de * a4.z * ((b & 4u) ? 1.f : p.slope));
+        v.w = fmaf(al, g4.w, de * a4.w * ((b & 8u) ? 1.f : p.slope));
+        if (ds) { accS[h].x += v.x; accS[h].y += v.y; accS[h].z += v.z; accS[h].w += v.w; }
+        else    { accT[h].x += v.x; accT[h].y += v.y; accT[h].z += v.z; accT[h].w += v.w; }
+      }
+    }
+    const bool dom_j = rvalid && p.mask[jc] != 0;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+      for (int off = 1; off < EP; off <<= 1) {
+        accS[h].x += __shfl_xor(accS[h].x, off); accS[h].y += __shfl_xor(accS[h].y, off);
+        accS[h].z += __shfl_xor(accS[h].z, off); accS[h].w += __shfl_xor(accS[h].w, off);
+        accT[h].x += __shfl_xor(accT[h].x, off); accT[h].y += __shfl_xor(accT[h].y, off);
+        accT[h].z += __shfl_xor(accT[h].z, off); accT[h].w += __shfl_xor(accT[h].w, off);
+      }
+      if (rvalid && sub == 0) {
+        const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * rs + 4 * h);
+        if (dom_j) { accS[h].x += ds4.x; accS[h].y += ds4.y; accS[h].z += ds4.z; accS[h].w += ds4.w; }
+        else       { accT[h].x += ds4.x; accT[h].y += ds4.y; accT[h].z += ds4.z; accT[h].w += ds4.w; }
+        *reinterpret_cast<float4*>(p.dh_t2s + j * rs + 4 * h) = accS[h];
+        *reinterpret_cast<float4*>(p.dh_s2t + j * rs + 4 * h) = accT[h];
+      }
+    }
+  }
+}
+
+template <int HEADS>
+int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
+  constexpr int EP = 8, RPB = 4 * (64 / EP);
+  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_heads_bwd_dst_kernel<HEADS, EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL((agg_heads_bwd_src_kernel<HEADS, EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int LF>
 int launch_pull(const PullParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / LF);
@@ -570,4 +777,35 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
   if (narrow) return launch_pull_narrow(p, st);
   const int nv = (D + 3) / 4;
   return nv <= 16 ? launch_pull<16>(p, st) : launch_pull<32>(p, st);
+}
+
+extern "C" size_t bgnn_aggregate_heads_bwd_workspace_bytes(int64_t N, int64_t E, int32_t heads) {
+  const size_t n = (size_t)(N > 0 ? N : 0), e = (size_t)(E > 0 ? E : 0), h = (size_t)(heads > 0 ? heads : 0);
+  return bgnn_align_up(32 * e, 256) + 2 * bgnn_align_up(sizeof(float) * n * h * 4, 256) + 256;
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
+                                                        const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                        const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                                                        int64_t N, int64_t E, int32_t D, int32_t heads, float negative_slope,
+                                                        const float* out, const float* state_ms, const float* grad_out,
+                                                        int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s,
+                                                        float* da_s2t, void* ws, size_t ws_bytes, void* stream) {
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_eid || !t_dst || !out || !state_ms ||
+      !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
+    return BGNN_E_NULL;
+  if (N < 0 || E < 0 || D < 1 || D > 4 || (heads != 2 && heads != 3)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
+      !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
+    return BGNN_E_ALIGN;
+  if (ws_bytes < bgnn_aggregate_heads_bwd_workspace_bytes(N, E, heads)) return BGNN_E_WORKSPACE;
+  if (N == 0) return 0;
+  uint4* rec = (uint4*)ws;
+  const size_t tb = bgnn_align_up(sizeof(float) * (size_t)N * (size_t)heads * 4, 256);
+  float* dstside = (float*)((char*)ws + bgnn_align_up((size_t)32 * (size_t)E, 256));
+  float* grbuf = (float*)((char*)dstside + tb);
+  HeadsBwdParams p{h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, state_ms, grad_out, log_softmax,
+                   t_rowptr, t_eid, t_dst, rec, dstside, grbuf, dh_t2s, dh_s2t, da_t2s, da_s2t};
+  hipStream_t st = (hipStream_t)stream;
+  return heads == 3 ? launch_heads_bwd<3>(p, st) : launch_heads_bwd<2>(p, st);
 }

@@ -199,6 +199,39 @@ class _AggregateFn(torch.autograd.Function):
         return dh_t2s, dh_s2t, da_t2s, da_s2t, None, None, None, None
 
 
+class _AggregateHeadsFn(torch.autograd.Function):
+    """Three narrow convs on one graph (KTGNN.py:432-435 under autograd) in ONE CSR walk forward (`agg_heads_kernel`, the
+    per-head log_softmax of :435 in its epilogue) and one walk per backward pass (`bgnn_adaptedconv_aggregate_heads_bwd_f32`);
+    the forward keeps only the rows' softmax state (24 B per node), no per-edge alpha.
+    inputs: `heads` (h_t2s, h_s2t) pairs of [N, 4] tables, then a_t2s / a_s2t as [heads, D] -> log-probs [N, heads, 4]."""
+
+    @staticmethod
+    def forward(ctx, csr, mask_u8, D, slope, a_t2s, a_s2t, *tables):
+        heads = len(tables) // 2
+        t2s = torch.cat(tables[0::2], dim=1)
+        s2t = torch.cat(tables[1::2], dim=1)
+        a_t2s, a_s2t = a_t2s.contiguous(), a_s2t.contiguous()
+        N = t2s.shape[0]
+        ms = torch.empty(N, heads, 2, dtype=torch.float32, device=t2s.device)
+        out = ops.adaptedconv_aggregate(t2s, s2t, a_t2s, a_s2t, csr, mask_u8, D, slope, heads=heads, log_softmax=True,
+                                        state_ms=ms, part=3)
+        ctx.save_for_backward(t2s, s2t, a_t2s, a_s2t, out, ms, mask_u8)
+        ctx.cfg = (csr, D, slope, heads)
+        return out.view(N, heads, 4)
+
+    @staticmethod
+    def backward(ctx, grad):
+        t2s, s2t, a_t2s, a_s2t, out, ms, mask_u8 = ctx.saved_tensors
+        csr, D, slope, heads = ctx.cfg
+        g = grad.reshape(out.shape).contiguous()
+        dt, ds, da_t, da_s = ops.adaptedconv_aggregate_heads_bwd(t2s, s2t, a_t2s, a_s2t, csr, mask_u8, D, heads, out, ms, g,
+                                                                 True, slope)
+        tabs = []
+        for h in range(heads):
+            tabs += [dt[:, 4 * h:4 * h + 4].contiguous(), ds[:, 4 * h:4 * h + 4].contiguous()]
+        return (None, None, None, None, da_t, da_s, *tabs)
+
+
 class _TransformFn(torch.autograd.Function):
     """(h_t2s, h_s2t) = domain-shifted dense transform (KTGNN.py:275-284) through the fused HIP kernel; the backward is
     written out by hand so that it is two plain GEMMs + row reductions instead of torch differentiating the
@@ -207,10 +240,11 @@ class _TransformFn(torch.autograd.Function):
       g = tanh(x.a_x + D.a_d) per gate,  D = mean_S x - mean_T x (a function of every row)."""
 
     @staticmethod
-    def forward(ctx, x, W_s, b_s, W_t, b_t, ag_s2t, ag_t2s, mask_u8, conv):
+    def forward(ctx, x, W_s, b_s, W_t, b_t, ag_s2t, ag_t2s, mask_u8, conv, sums=None):
         xp = _pad_cols4(x)
         din_pad = xp.shape[1]
-        sums = ops.domain_sums(xp, mask_u8)
+        if sums is None:                 # `sums`: the domain sums of this x if another conv on the same input already has them
+            sums = ops.domain_sums(xp, mask_u8)
         delta = ops.domain_delta(sums, din_pad)
         h_t2s, h_s2t = ops.adaptedconv_transform(xp, mask_u8, delta, conv.packed(din_pad))[0]
         ctx.save_for_backward(x, W_s, W_t, ag_s2t, ag_t2s, mask_u8, delta, sums)
@@ -280,7 +314,7 @@ class _TransformFn(torch.autograd.Function):
                 dX = dX + torch.where(m, 1.0 / n_s, -1.0 / n_t)[:, None] * ddl[None, :]   # through the domain means
         db_s = ex[D:2 * D, 2] if ctx.has_bias[0] else None
         db_t = ex[:D, 2] if ctx.has_bias[1] else None
-        return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None
+        return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None
 
 
 class AdaptedConv(nn.Module):
@@ -360,6 +394,11 @@ class AdaptedConv(nn.Module):
         return ops.adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, self.out_channels,
                                          self.negative_slope, n_dst=n_dst, want_alpha=want_alpha,
                                          ep_scale=sc, ep_shift=sh, ep_relu=relu, colsum=colsum)
+
+    def _transform_autograd(self, x, mask_u8, sums=None):
+        """the differentiable transform alone -> (h_t2s, h_s2t) [N, pad4(D)]"""
+        return _TransformFn.apply(x, self.lin_s.weight, self.lin_s.bias, self.lin_t.weight, self.lin_t.bias,
+                                  self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self, sums)
 
     def _forward_autograd(self, x, mask, mask_u8, csr):
         """Differentiable path: fused HIP transform + fused HIP aggregation, each a `torch.autograd.Function`."""
@@ -623,6 +662,22 @@ class KTGNN_no_complement(nn.Module):
         x, sums_h = self._hidden(x, csr, central_mask, want_sums=True)
         x = x.contiguous()
         mask_u8 = _as_u8(central_mask).contiguous()
+        C = self.clf_base.out_channels
+        if (self.training and torch.is_grad_enabled() and not (self.clf_base.root_weight or self.clf_base.normalize)
+                and ops.heads_log_softmax_supported(3, C) and x.dtype == torch.float32
+                and os.environ.get("BGNN_FUSED_TRAIN_HEADS", "1") != "0"):
+            # training step (main_graph_knowledge_transfer.py:39-68): the three classifier convs share the graph -> one CSR
+            # walk forward and one per backward pass for all three; h's domain sums are formed once for both convs on h
+            sums_x = ops.domain_sums(_pad_cols4(x.detach()), mask_u8)
+            l0, bn, _, l3 = self.clf_transformer
+            xt = l3(bn_relu_dropout_train(l0(x), bn, True, 0.0)).contiguous()
+            tabs = (*self.clf_base._transform_autograd(x, mask_u8, sums_x), *self.clf_target._transform_autograd(x, mask_u8, sums_x),
+                    *self.clf_target._transform_autograd(xt, mask_u8))
+            cs = (self.clf_base, self.clf_target, self.clf_target)
+            a_t = torch.stack([c.a_f_t2s.weight.reshape(-1) for c in cs])
+            a_s = torch.stack([c.a_f_s2t.weight.reshape(-1) for c in cs])
+            logp = _AggregateHeadsFn.apply(csr, mask_u8, C, self.clf_base.negative_slope, a_t, a_s, *tabs)[:, :, :C]
+            return logp[:, 0], logp[:, 1], logp[:, 2], None                                             # :432,:434,:433
         if self.clf_base.root_weight or self.clf_base.normalize or torch.is_grad_enabled() or self.training:
             logits_base = self.clf_base(x, None, central_mask=central_mask, csr=csr)                      # :432
             logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr)                  # :434

@@ -397,6 +397,29 @@ def adaptedconv_aggregate_bwd(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, out, 
     return dh_t2s, dh_s2t, da_t2s, da_s2t
 
 
+def adaptedconv_aggregate_heads_bwd(t2s, s2t, a_t2s, a_s2t, csr, mask_u8, D, heads, out, state_ms, grad_out, log_softmax,
+                                    negative_slope=0.1):
+    """backward of `adaptedconv_aggregate(..., heads=2|3, part=3)` for interleaved narrow heads ([N, heads*4] tables):
+    -> (dh_t2s, dh_s2t [N, heads*4], da_t2s, da_s2t [heads, D]); one CSR walk per pass for all heads."""
+    lib = L.lib()
+    dev = t2s.device
+    N = csr.num_nodes
+    assert t2s.shape == (N, heads * 4) and t2s.is_contiguous() and s2t.is_contiguous() and out.is_contiguous() and grad_out.is_contiguous()
+    da_t2s = torch.zeros(heads, D, dtype=torch.float32, device=dev)
+    da_s2t = torch.zeros(heads, D, dtype=torch.float32, device=dev)
+    dh_t2s, dh_s2t = torch.empty_like(t2s), torch.empty_like(s2t)
+    t_rowptr, t_eid, t_dst = csr.transposed()
+    wsb = lib.bgnn_aggregate_heads_bwd_workspace_bytes(N, csr.num_edges, heads)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = lib.bgnn_adaptedconv_aggregate_heads_bwd_f32(
+        L.ptr(t2s), L.ptr(s2t), L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(mask_u8),
+        L.ptr(t_rowptr), L.ptr(t_eid), L.ptr(t_dst), N, csr.num_edges, D, heads, float(negative_slope),
+        L.ptr(out), L.ptr(state_ms), L.ptr(grad_out), int(bool(log_softmax)), L.ptr(dh_t2s), L.ptr(dh_s2t),
+        L.ptr(da_t2s), L.ptr(da_s2t), L.ptr(ws), wsb, L.stream())
+    L.check(rc, "bgnn_adaptedconv_aggregate_heads_bwd_f32")
+    return dh_t2s, dh_s2t, da_t2s, da_s2t
+
+
 def l2_normalize_rows(q, eps=1e-8):
     out = torch.empty_like(q)
     rc = L.lib().bgnn_l2_normalize_rows_f32(L.ptr(q), q.shape[0], q.shape[1], float(eps), L.ptr(out), L.stream())

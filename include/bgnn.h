@@ -185,7 +185,9 @@ int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, 
  * alpha_opt ([E'] in CSR order) is optional (tests / backward).
  * Two-part rows (multi-GPU overlap): part = 1 visits a row's first edge list and parks the online-softmax state
  * ((max, sum) in state_ms_opt [rows][2], the raw accumulator in out); part = 2 resumes from it over a second
- * edge list (another rowptr/col pair) and finishes the row.  part = 0 is the ordinary single launch.  In part = 1 the
+ * edge list (another rowptr/col pair) and finishes the row.  part = 0 is the ordinary single launch; part = 3 (narrow
+ * interleaved heads only) is a single launch that also leaves the finished rows' (max, sum) in state_ms_opt [rows][heads][2]
+ * for bgnn_adaptedconv_aggregate_heads_bwd_f32.  In part = 1 the
  * rows [row_begin, park_begin) have no second part and are finished right away (epilogue, colsum), rows
  * [park_begin, row_end) are parked: one launch serves a rank's interior and boundary rows (park_begin = row_begin
  * parks every row).
@@ -234,6 +236,22 @@ int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s
                                             const float* grad_out, int64_t ldg,
                                             float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
                                             void* ws, size_t ws_bytes, void* stream);
+
+/* Pull-form backward for `heads` (2 or 3) interleaved narrow convs evaluated together (KT-GNN's classifier stage under
+ * autograd: clf_base(x), clf_target(x), clf_target(T(x)), KTGNN.py:432-435, share the graph): tables / out / grad_out / dH are
+ * [N][heads][4], a_* and da_* [heads][D] (da accumulated: caller zero-fills), D <= 4.  `state_ms` [N][heads][2] is the finished
+ * rows' softmax state (max, sum) that bgnn_adaptedconv_aggregate_f32 leaves with part = 3; alpha is rebuilt from it, no per-edge
+ * array is kept by the forward.  log_softmax != 0: `out` holds the fused log-probabilities (ep_relu = 2) and grad_out is
+ * dL/dlogp -- the row-local adjoint is applied first.  Every dH row is written exactly once (deterministic).
+ * ws: bgnn_aggregate_heads_bwd_workspace_bytes(N, E', heads). */
+size_t bgnn_aggregate_heads_bwd_workspace_bytes(int64_t N, int64_t E, int32_t heads);
+int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
+                                             const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                             const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                                             int64_t N, int64_t E, int32_t D, int32_t heads, float negative_slope,
+                                             const float* out, const float* state_ms, const float* grad_out,
+                                             int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s,
+                                             float* da_s2t, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a2,a3,a5,a6,a7) kNN bridge: pair scoring + per-query top-k.

@@ -237,3 +237,41 @@ def test_fused_bn_relu_dropout_matches_torch_formula(n, d, relu, p):
     if p > 0:                                          # a second call draws a different mask
         y2 = bn_relu_dropout_train(xg, bn, relu, p)
         assert not torch.equal(y2 == 0, y == 0)
+
+
+@pytest.mark.parametrize("D,n,seed", [(2, 3000, 0), (4, 1500, 1), (3, 700, 2), (1, 400, 3), (2, 20000, 4)])
+def test_three_head_aggregation_backward_equals_three_single_heads(D, n, seed):
+    """`_AggregateHeadsFn` (one CSR walk for the three classifier convs, log_softmax fused, alpha rebuilt from the rows'
+    softmax state) vs three `_AggregateFn` + F.log_softmax: outputs and every gradient (tables, attention vectors)."""
+    import torch.nn.functional as F
+    from bridged_gnn_amd import ops, synth
+    from bridged_gnn_amd.ktgnn import _AggregateFn, _AggregateHeadsFn
+    ei, mask = synth.random_multigraph(n, 9 * n, frac_src=0.4, n_isolated=3, seed=seed)
+    rng = np.random.default_rng(seed)
+    csr = ops.build_dst_csr(_t(ei), n)
+    mask_u8 = _t(mask).to(torch.uint8)
+
+    def leaves():
+        r = np.random.default_rng(100 + seed)
+        tabs = []
+        for _ in range(6):
+            t = np.zeros((n, 4), np.float32)
+            t[:, :D] = r.standard_normal((n, D)).astype(np.float32)
+            tabs.append(_t(t).requires_grad_(True))
+        a_t = _t(r.standard_normal((3, D)).astype(np.float32)).requires_grad_(True)
+        a_s = _t(r.standard_normal((3, D)).astype(np.float32)).requires_grad_(True)
+        return tabs, a_t, a_s
+    w = _t(rng.standard_normal((n, 3, D)).astype(np.float32))
+    tabs, a_t, a_s = leaves()
+    logp = _AggregateHeadsFn.apply(csr, mask_u8, D, 0.1, a_t, a_s, *tabs)[:, :, :D]
+    (logp * w).sum().backward()
+    tabs2, a_t2, a_s2 = leaves()
+    outs = [F.log_softmax(_AggregateFn.apply(tabs2[2 * h], tabs2[2 * h + 1], a_t2[h], a_s2[h], csr, mask_u8, D, 0.1)[:, :D], dim=1)
+            for h in range(3)]
+    ref = torch.stack(outs, dim=1)
+    (ref * w).sum().backward()
+    assert _rel(logp.detach().double(), ref.detach().double()) < 1e-5
+    for h in range(6):
+        assert _rel(tabs[h].grad.double(), tabs2[h].grad.double()) < 2e-5, f"table {h}"
+        assert float(tabs[h].grad[:, D:].abs().max()) == 0.0 if D < 4 else True
+    assert _rel(a_t.grad.double(), a_t2.grad.double()) < 1e-4 and _rel(a_s.grad.double(), a_s2.grad.double()) < 1e-4
