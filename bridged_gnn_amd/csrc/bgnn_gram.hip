@@ -122,6 +122,205 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(GramParams g) {
   }
 }
 
+// bf16 x 3 variant for p > 32 (the hidden conv's [260, N] x [N, 128] and the Linears' [128, N] x [N, 128] weight gradients).
+// fp32 MFMA runs on the vector ALU (64 cycles per 32x32x2 step, and the staging arithmetic competes with it: 0.98 ms for
+// p = 260); here every fp32 value is split exactly into three bf16 pieces while it is staged (hi + mid + lo = the 24-bit
+// significand) and a product is the six bf16 MFMAs whose pieces are >= 2^-24 relative -- the matrix cores do 16 rows of
+// the reduction in 6 x 32 cycles instead of 8 x 64.  The reduction index (the node) is the ROW of both operands in memory, but
+// an MFMA operand wants 8 consecutive reduction indices per lane: the LDS image stays row-major [piece][node][column]
+// (8-byte writes of 4 columns) and the operands are fetched with the transposing LDS read `ds_read_b64_tr_b16` (per 16 lanes
+// a 4 x 16 block, delivered column-major).  Row pitch = 64 B (mod 256 B): the four rows of a block fall on disjoint banks.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int GB_RT = 16;       // nodes per LDS tile = one k-step of v_mfma_f32_32x32x16_bf16
+
+__host__ __device__ inline int gram_bf16_pitch(int pa) {       // bf16 elements per row: 32 (mod 128)
+  int P = pa * 32 + 128;
+  while (P % 128 != 32) P += 32;
+  return P;
+}
+
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* base /* this lane's address for rows 0..3 */, int row4_stride) {
+  // two transposing reads: reduction rows 8fh + 0..3 and 8fh + 4..7 of this lane's column
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + row4_stride));
+  const bf16x4 l = __builtin_bit_cast(bf16x4, lo), h = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+  r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; r[3] = l[3]; r[4] = h[0]; r[5] = h[1]; r[6] = h[2]; r[7] = h[3];
+  return r;
+}
+
+// Eight waves with two roles (wave-uniform): waves 0..3 only multiply -- wave w owns output columns 32w..32w+31 and all PA row
+// blocks (the MFMA chains of two row blocks interleaved: a lone dependent bf16 chain issues at half rate) -- and waves 4..7
+// only stage (global loads two tiles ahead, the three-way split, LDS writes).  A SIMD then holds one wave of each kind and the
+// conversion arithmetic runs beside the matrix work instead of in front of it (same-role waves between two barriers run the
+// two halves one after the other: measured 0.65 ms for p = 260; opposite-order halves in one code path spilled).
+template <int PA>
+__global__ __launch_bounds__(512) void gram_bf16_kernel(GramParams g) {
+  constexpr int NT = 256;                               // threads of one role
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // bf16 [2][3][GB_RT][P]
+  __bf16* smb = reinterpret_cast<__bf16*>(sm);
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool stager = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int pa = (g.p + 31) / 32;
+  const int ldA = pa * 32;
+  const int P = gram_bf16_pitch(pa);
+  const int piece = GB_RT * P, bufsz = 3 * piece;       // bf16 elements
+  const int nA4 = g.p / 4, nB4 = g.q / 4;
+  const int64_t rows_per_blk = (g.N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r1 = min(g.N, r0 + rows_per_blk);
+  const int ntile = r1 > r0 ? (int)((r1 - r0 + GB_RT - 1) / GB_RT) : 0;
+  for (int t = threadIdx.x; t < bufsz; t += 512) sm[t] = 0.f;    // (2 buffers x bufsz bf16 = bufsz floats) padding columns stay zero
+  __syncthreads();
+
+  if (stager) {
+    const int n4 = nA4 + nB4, nslot = GB_RT * n4;
+    constexpr int MAXS = (GB_RT * (PA * 32 + 128) / 4 + NT - 1) / NT;
+    int srow[MAXS], slds[MAXS], scol[MAXS];
+    unsigned int isA = 0;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+      // slots past the tile wrap around: such a thread stages an element a second time (the same value to the same place)
+      // instead of branching around a load / store
+      const int sidx = (tid + NT * j) % nslot;
+      {
+        const int r = sidx / n4, c = sidx % n4;
+        srow[j] = r;
+        if (c < nA4) { isA |= 1u << j; scol[j] = c * 4; slds[j] = r * P + c * 4; }
+        else { scol[j] = (c - nA4) * 4; slds[j] = r * P + ldA + (c - nA4) * 4; }
+      }
+    }
+    // two register sets: tiles u+2 and u+3 are in flight while tile u is multiplied.  The loads are branch-free (tail rows
+    // re-read a valid row; their values are zeroed when they are stored): a load inside a lane-masked branch
+    // whose result is assigned there makes the compiler wait for it on the spot, i.e. one load in flight at a time
+    float4 stA[MAXS], stB[MAXS];
+    unsigned int okA = 0, okB = 0;
+    auto gload = [&](int t, float4 (&st)[MAXS], unsigned int& okm) {
+      okm = 0;
+#pragma unroll
+      for (int j = 0; j < MAXS; ++j) {
+        const int64_t row = r0 + (int64_t)t * GB_RT + srow[j];
+        const bool a = (isA >> j) & 1u;
+        okm |= row < r1 ? 1u << j : 0u;
+        st[j] = *reinterpret_cast<const float4*>((a ? g.A : g.B) + (row < r1 ? row : r1 - 1) * (a ? g.lda : g.ldb) + scol[j]);
+      }
+    };
+    auto sstore = [&](int buf, const float4 (&st)[MAXS], unsigned int okm) {
+      __bf16* base = smb + buf * bufsz;
+#pragma unroll
+      for (int j = 0; j < MAXS; ++j) {                   // branch-free (see gload)
+        {
+          const bool ok = (okm >> j) & 1u;
+          const float vf[4] = {ok ? st[j].x : 0.f, ok ? st[j].y : 0.f, ok ? st[j].z : 0.f, ok ? st[j].w : 0.f};
+          bf16x4 ph, pm, pl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)vf[e];
+            const float r1_ = vf[e] - (float)h;
+            const __bf16 m = (__bf16)r1_;
+            ph[e] = h; pm[e] = m; pl[e] = (__bf16)(r1_ - (float)m);
+          }
+          *reinterpret_cast<bf16x4*>(base + slds[j]) = ph;
+          *reinterpret_cast<bf16x4*>(base + piece + slds[j]) = pm;
+          *reinterpret_cast<bf16x4*>(base + 2 * piece + slds[j]) = pl;
+        }
+      }
+    };
+    if (ntile > 0) { gload(0, stA, okA); sstore(0, stA, okA); }
+    if (ntile > 1) gload(1, stA, okA);
+    if (ntile > 2) gload(2, stB, okB);
+    int t = 0;
+    for (; t + 4 < ntile; t += 2) {                      // steady state without conditions: exact s_waitcnt vmcnt counts
+      __syncthreads();                                   // tile t complete in buffer 0; nobody reads buffer 1 any more
+      sstore(1, stA, okA);
+      gload(t + 3, stA, okA);
+      __syncthreads();
+      sstore(0, stB, okB);
+      gload(t + 4, stB, okB);
+    }
+    for (; t < ntile; t += 2) {
+      __syncthreads();
+      if (t + 1 < ntile) sstore(1, stA, okA);
+      if (t + 3 < ntile) gload(t + 3, stA, okA);
+      if (t + 1 < ntile) {
+        __syncthreads();
+        if (t + 2 < ntile) sstore(0, stB, okB);
+        if (t + 4 < ntile) gload(t + 4, stB, okB);
+      }
+    }
+    return;
+  }
+
+  f32x16 acc[PA];
+#pragma unroll
+  for (int a = 0; a < PA; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  const bool wave_on = wave * 32 < g.q;                  // wave-uniform
+  // transposing-read address of this lane inside a 32-column operand block: 16-lane group gq = lane >> 4 covers columns
+  // 16 (gq & 1) .. +15 and reduction rows 8 (gq >> 1) .. ; lane 4q + pp of the group points at row q, columns 4pp .. 4pp + 3
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int toff = (8 * (gq >> 1) + (i16 >> 2)) * P + 16 * (gq & 1) + 4 * (i16 & 3);
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();                                     // (the same barrier sequence as the staging waves: one per tile)
+    // (every lane of the wave runs the reads: the transposing read needs EXEC all ones; the conditions are wave-uniform)
+    if (wave_on) {
+      const __bf16* base = smb + (t & 1) * bufsz + toff;
+      const __bf16* bb = base + ldA + wave * 32;
+      const bf16x8 bh = tr_read8(bb, 4 * P), bm = tr_read8(bb + piece, 4 * P), bl = tr_read8(bb + 2 * piece, 4 * P);
+#pragma unroll
+      for (int a = 0; a < PA; a += 2) {
+        const bool on0 = a < pa, on1 = (a + 1 < PA) && (a + 1 < pa);
+        if (on0 && on1) {
+          const __bf16* ab = base + a * 32;
+          const bf16x8 ah = tr_read8(ab, 4 * P), am = tr_read8(ab + piece, 4 * P), al = tr_read8(ab + 2 * piece, 4 * P);
+          const bf16x8 ch = tr_read8(ab + 32, 4 * P), cm = tr_read8(ab + 32 + piece, 4 * P), cl = tr_read8(ab + 32 + 2 * piece, 4 * P);
+          const int a1 = a + 1 < PA ? a + 1 : a;           // (unrolled: a compile-time register index)
+          // smallest terms first; dropped: mid*lo, lo*mid, lo*lo (< 2^-24 relative)
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, bh, acc[a1], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, bl, acc[a1], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cm, bm, acc[a1], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cm, bh, acc[a1], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, bm, acc[a1], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[a], 0, 0, 0);
+          acc[a1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, bh, acc[a1], 0, 0, 0);
+        } else if (on0) {
+          const __bf16* ab = base + a * 32;
+          const bf16x8 ah = tr_read8(ab, 4 * P), am = tr_read8(ab + piece, 4 * P), al = tr_read8(ab + 2 * piece, 4 * P);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[a], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[a], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[a], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[a], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[a], 0, 0, 0);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[a], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (wave_on) {
+    float* out = g.part + (int64_t)blockIdx.x * g.p * g.q;
+    const int col = wave * 32 + fr;
+#pragma unroll
+    for (int a = 0; a < PA; ++a)
+      if (a < pa) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (i < g.p && col < g.q) out[(int64_t)i * g.q + col] = acc[a][r];
+        }
+      }
+  }
+}
+
 __global__ void gram_reduce_kernel(const float* __restrict__ part, int nblk, int64_t pq, float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= pq) return;
@@ -144,8 +343,13 @@ static size_t gram_lds_bytes(int p) {
   const int pa = (p + 31) / 32;
   return sizeof(float) * 2 * GR_RT * (size_t)(pa * 32 + 128 + ((pa & 1) ? 0 : 32));
 }
+static size_t gram_bf16_lds_bytes(int p) {
+  const int pa = (p + 31) / 32;
+  return sizeof(__bf16) * 2 * 3 * GB_RT * (size_t)gram_bf16_pitch(pa);
+}
+static bool gram_use_bf16(int p) { return p > 32; }
 static int gram_blocks(int p) {
-  int per_cu = (int)((150 * 1024) / gram_lds_bytes(p));
+  int per_cu = (int)((150 * 1024) / (gram_use_bf16(p) ? gram_bf16_lds_bytes(p) : gram_lds_bytes(p)));
   per_cu = per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu;
   return 256 * per_cu;
 }
@@ -289,11 +493,11 @@ extern "C" int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float
   if (ws_bytes < bgnn_gram_workspace_bytes(p, q)) return BGNN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t pq = (int64_t)p * q;
-  int nblk = (int)((N + GR_RT - 1) / GR_RT);
+  int nblk = (int)((N + GR_RT - 1) / GR_RT);          // (a block's slice is at least one fp32 tile = two bf16 tiles)
   if (nblk > gram_blocks(p)) nblk = gram_blocks(p);
   if (nblk < 1) nblk = 1;
   GramParams g{A, lda, p, B, ldb, q, N, (float*)ws};
-  const size_t sh = gram_lds_bytes(p);
+  const size_t sh = gram_use_bf16(p) ? gram_bf16_lds_bytes(p) : gram_lds_bytes(p);
   const int pa = (p + 31) / 32;
 #define BGNN_GRAM(PA)                                                                                                  \
   do {                                                                                                                 \
@@ -303,8 +507,17 @@ extern "C" int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float
     if (attr != hipSuccess) return (int)attr;                                                                          \
     hipLaunchKernelGGL(gram_partial_kernel<PA>, dim3(nblk), dim3(256), sh, st, g);                                     \
   } while (0)
-  if (pa <= 1) BGNN_GRAM(1); else if (pa <= 4) BGNN_GRAM(4); else BGNN_GRAM(GR_PA);
+#define BGNN_GRAM_BF16(PA)                                                                                             \
+  do {                                                                                                                 \
+    static int attr_done[BGNN_MAX_DEVICES];                                                                            \
+    const hipError_t attr = bgnn_set_max_dynamic_lds(reinterpret_cast<const void*>(gram_bf16_kernel<PA>),           \
+                                                     160 * 1024 - 1024, attr_done);                                    \
+    if (attr != hipSuccess) return (int)attr;                                                                          \
+    hipLaunchKernelGGL((gram_bf16_kernel<PA>), dim3(nblk), dim3(512), sh, st, g);                                   \
+  } while (0)
+  if (pa <= 1) BGNN_GRAM(1); else if (pa <= 4) BGNN_GRAM_BF16(4); else BGNN_GRAM_BF16(GR_PA);
 #undef BGNN_GRAM
+#undef BGNN_GRAM_BF16
   BGNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((pq + 255) / 256)), dim3(256), 0, st, (const float*)ws, nblk, pq, out);
   BGNN_LAUNCH_CHECK();
