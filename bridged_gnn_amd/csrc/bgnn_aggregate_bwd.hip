@@ -488,21 +488,23 @@ static int launch_pull_narrow(const PullParams& p, hipStream_t st) {
 
 // Interleaved narrow heads (KT-GNN's classifier stage under autograd: clf_base(x), clf_target(x), clf_target(T(x)) share the
 // graph): the pull form for HEADS convs in ONE walk per pass.  Tables / out / grad_out / dH are [N][HEADS][4] (48-byte rows
-// for three heads), the attention vectors [HEADS][D].  Nothing per edge is kept by the forward: alpha is rebuilt from the
-// finished rows' softmax state (m, s) that the forward leaves in `state_ms` (bgnn_adaptedconv_aggregate_f32, part 3), and with
-// `log_softmax` the incoming gradient is taken through the row-local log_softmax first: gr = g - exp(logp) * sum(g) -- then
-// t_i = gr . out_i can be formed from the log-probabilities themselves (sum(gr) = 0 cancels the unknown shift).
-// Record per edge (32 B): HEADS x {alpha, de} | bit 31 = domain of the destination, bits 4h..4h+3 = signs of h_j + h_i.
+// for three heads), the attention vectors [HEADS][D].  Nothing per EDGE is kept, neither by the forward nor between the passes:
+// alpha is rebuilt from the finished rows' softmax state (m, s) that the forward leaves in `state_ms`
+// (bgnn_adaptedconv_aggregate_f32, part 3), and pass B recomputes alpha / de of an edge j -> i from a 144-byte per-NODE record
+// of i that pass A leaves ({h_i, gr_i, m, 1/s, t_i, domain}: 144 MB for C4, L2 / MALL friendly) instead of streaming a
+// 32-byte record per edge through HBM twice (672 MB written in destination order, read in source order: measured 1.8 ms for
+// the two passes, of which ~1 ms was that stream).  With `log_softmax` the incoming gradient is taken through the row-local
+// log_softmax first: gr = g - exp(logp) * sum(g) -- then t_i = gr . out_i can be formed from the log-probabilities themselves
+// (sum(gr) = 0 cancels the unknown shift).
 struct HeadsBwdParams {
   const float* h_t2s; const float* h_s2t;
   const float* a_t2s; const float* a_s2t;
   const int32_t* rowptr; const int32_t* col; const uint8_t* mask;
   int64_t N; int32_t D; float slope;
   const float* out; const float* state_ms; const float* gout; int log_softmax;
-  const int32_t* t_rowptr; const int32_t* t_eid; const int32_t* t_dst;
-  uint4* rec;            // [E'][2]
+  const int32_t* t_rowptr; const int32_t* t_dst;
+  float4* node;          // [N][3 * HEADS]: h_i[HEADS] | gr_i[HEADS] | per head (m, 1/s, t_i, domain)
   float* dstside;        // [N][HEADS][4]
-  float* grbuf;          // [N][HEADS][4]  gradient w.r.t. the aggregation output (after the log_softmax adjoint)
   float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
 };
 
@@ -513,7 +515,22 @@ __device__ __forceinline__ float4 mask_cols(float4 v, int D) {
   return v;
 }
 
-template <int HEADS, int EP>
+// alpha and de of one edge and head from the two end points (the forward's logit, same operation order)
+struct EdgeTerm { float al, de; float4 lk, lz; };   // lk: leaky'(z) per column, lz: leaky(z)
+__device__ __forceinline__ EdgeTerm edge_term(const float4& hj, const float4& hi, const float4& a4, const float4& gr, float m,
+                                              float inv, float ti, float slope) {
+  const float zx = hj.x + hi.x, zy = hj.y + hi.y, zz = hj.z + hi.z, zw = hj.w + hi.w;
+  EdgeTerm r;
+  r.lk = make_float4(zx > 0.f ? 1.f : slope, zy > 0.f ? 1.f : slope, zz > 0.f ? 1.f : slope, zw > 0.f ? 1.f : slope);
+  r.lz = make_float4(zx * r.lk.x, zy * r.lk.y, zz * r.lk.z, zw * r.lk.w);
+  float t = a4.x * r.lz.x;
+  t = fmaf(a4.y, r.lz.y, t); t = fmaf(a4.z, r.lz.z, t); t = fmaf(a4.w, r.lz.w, t);
+  r.al = __expf(t - m) * inv;
+  r.de = r.al * (gr.x * hj.x + gr.y * hj.y + gr.z * hj.z + gr.w * hj.w - ti);
+  return r;
+}
+
+template <int HEADS, int EP, int U>
 __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p) {
   constexpr int GPW = 64 / EP, RPB = 4 * GPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -558,34 +575,33 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p
       mh[h] = p.state_ms[2 * (ic * HEADS + h)];
       inv[h] = 1.f / (p.state_ms[2 * (ic * HEADS + h) + 1] + 1e-16f);
       accd[h] = accz[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.grbuf + i * rs + 4 * h) = gi;
-    }
-    for (int32_t e = beg + sub; e < end; e += EP) {
-      const int32_t j = p.col[e];
-      float4 hj[HEADS];
-#pragma unroll
-      for (int h = 0; h < HEADS; ++h) hj[h] = *reinterpret_cast<const float4*>(H + (int64_t)j * rs + 4 * h);
-      uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-      uint32_t bits = dom_s ? 0x80000000u : 0u;
-#pragma unroll
-      for (int h = 0; h < HEADS; ++h) {
-        const float zx = hj[h].x + hi[h].x, zy = hj[h].y + hi[h].y, zz = hj[h].z + hi[h].z, zw = hj[h].w + hi[h].w;
-        const bool px = zx > 0.f, py = zy > 0.f, pz = zz > 0.f, pw = zw > 0.f;
-        const float lx = px ? zx : zx * p.slope, ly = py ? zy : zy * p.slope, lz = pz ? zz : zz * p.slope, lw = pw ? zw : zw * p.slope;
-        float t = a4[h].x * lx;                       // the forward's logit, same operation order
-        t = fmaf(a4[h].y, ly, t); t = fmaf(a4[h].z, lz, t); t = fmaf(a4[h].w, lw, t);
-        const float al = __expf(t - mh[h]) * inv[h];
-        const float de = al * (gr[h].x * hj[h].x + gr[h].y * hj[h].y + gr[h].z * hj[h].z + gr[h].w * hj[h].w - ti[h]);
-        accd[h].x += de * a4[h].x * (px ? 1.f : p.slope); accd[h].y += de * a4[h].y * (py ? 1.f : p.slope);
-        accd[h].z += de * a4[h].z * (pz ? 1.f : p.slope); accd[h].w += de * a4[h].w * (pw ? 1.f : p.slope);
-        accz[h].x += de * lx; accz[h].y += de * ly; accz[h].z += de * lz; accz[h].w += de * lw;
-        w[2 * h] = __float_as_uint(al); w[2 * h + 1] = __float_as_uint(de);
-        bits |= ((px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u) | (pw ? 8u : 0u)) << (4 * h);
+      if (rvalid && sub == 0) {
+        float4* nd = p.node + i * (3 * HEADS);
+        nd[h] = hi[h];
+        nd[HEADS + h] = gi;
+        nd[2 * HEADS + h] = make_float4(mh[h], inv[h], ti[h], dom_s ? 1.f : 0.f);
       }
-      w[7] = bits;
-      uint4* r = p.rec + (int64_t)e * 2;
-      r[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      r[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    for (int32_t e0 = beg + sub; e0 < end; e0 += EP * U) {
+      int32_t jj[U];
+      float4 hj[U][HEADS];
+#pragma unroll
+      for (int u = 0; u < U; ++u) jj[u] = e0 + u * EP < end ? p.col[e0 + u * EP] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) hj[u][h] = *reinterpret_cast<const float4*>(H + (int64_t)max(jj[u], 0) * rs + 4 * h);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (jj[u] < 0) continue;
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+          const EdgeTerm t = edge_term(hj[u][h], hi[h], a4[h], gr[h], mh[h], inv[h], ti[h], p.slope);
+          accd[h].x += t.de * a4[h].x * t.lk.x; accd[h].y += t.de * a4[h].y * t.lk.y;
+          accd[h].z += t.de * a4[h].z * t.lk.z; accd[h].w += t.de * a4[h].w * t.lk.w;
+          accz[h].x += t.de * t.lz.x; accz[h].y += t.de * t.lz.y; accz[h].z += t.de * t.lz.z; accz[h].w += t.de * t.lz.w;
+        }
+      }
     }
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
@@ -613,7 +629,7 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p
   }
 }
 
-template <int HEADS, int EP>
+template <int HEADS, int EP, int U>
 __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p) {
   constexpr int GPW = 64 / EP, RPB = 4 * GPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -636,27 +652,38 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
     const bool rvalid = j < p.N;
     const int64_t jc = rvalid ? j : 0;
     const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
-    float4 accS[HEADS], accT[HEADS];
+    float4 hS[HEADS], hT[HEADS], accS[HEADS], accT[HEADS];   // row j of both tables: the destination's domain picks one
 #pragma unroll
-    for (int h = 0; h < HEADS; ++h) accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int32_t k = beg + sub; k < end; k += EP) {
-      const int32_t e = p.t_eid[k], i = p.t_dst[k];
-      const uint4 r0 = p.rec[(int64_t)e * 2], r1 = p.rec[(int64_t)e * 2 + 1];
-      const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-      const bool ds = (w[7] & 0x80000000u) != 0u;
+    for (int h = 0; h < HEADS; ++h) {
+      hS[h] = *reinterpret_cast<const float4*>(p.h_t2s + jc * rs + 4 * h);
+      hT[h] = *reinterpret_cast<const float4*>(p.h_s2t + jc * rs + 4 * h);
+      accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int32_t k0 = beg + sub; k0 < end; k0 += EP * U) {
+      int32_t ii[U];
+      float4 nd[U][3 * HEADS];
 #pragma unroll
-      for (int h = 0; h < HEADS; ++h) {
-        const float4 g4 = *reinterpret_cast<const float4*>(p.grbuf + (int64_t)i * rs + 4 * h);
-        const float al = __uint_as_float(w[2 * h]), de = __uint_as_float(w[2 * h + 1]);
-        const uint32_t b = w[7] >> (4 * h);
-        const float4 a4 = ds ? aS[h] : aT[h];
-        float4 v;
-        v.x = fmaf(al, g4.x, de * a4.x * ((b & 1u) ? 1.f : p.slope));
-        v.y = fmaf(al, g4.y, de * a4.y * ((b & 2u) ? 1.f : p.slope));
-        v.z = fmaf(al, g4.z, de * a4.z * ((b & 4u) ? 1.f : p.slope));
-        v.w = fmaf(al, g4.w, de * a4.w * ((b & 8u) ? 1.f : p.slope));
-        if (ds) { accS[h].x += v.x; accS[h].y += v.y; accS[h].z += v.z; accS[h].w += v.w; }
-        else    { accT[h].x += v.x; accT[h].y += v.y; accT[h].z += v.z; accT[h].w += v.w; }
+      for (int u = 0; u < U; ++u) ii[u] = k0 + u * EP < end ? p.t_dst[k0 + u * EP] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 3 * HEADS; ++c) nd[u][c] = p.node[(int64_t)max(ii[u], 0) * (3 * HEADS) + c];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ii[u] < 0) continue;
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+          const float4 st = nd[u][2 * HEADS + h];        // (m, 1/s, t_i, domain of i)
+          const bool ds = st.w != 0.f;
+          const float4 a4 = ds ? aS[h] : aT[h];
+          const float4 gr = nd[u][HEADS + h];
+          const EdgeTerm t = edge_term(ds ? hS[h] : hT[h], nd[u][h], a4, gr, st.x, st.y, st.z, p.slope);
+          float4 v;
+          v.x = fmaf(t.al, gr.x, t.de * a4.x * t.lk.x); v.y = fmaf(t.al, gr.y, t.de * a4.y * t.lk.y);
+          v.z = fmaf(t.al, gr.z, t.de * a4.z * t.lk.z); v.w = fmaf(t.al, gr.w, t.de * a4.w * t.lk.w);
+          if (ds) { accS[h].x += v.x; accS[h].y += v.y; accS[h].z += v.z; accS[h].w += v.w; }
+          else    { accT[h].x += v.x; accT[h].y += v.y; accT[h].z += v.z; accT[h].w += v.w; }
+        }
       }
     }
     const bool dom_j = rvalid && p.mask[jc] != 0;
@@ -682,15 +709,26 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
 
 template <int HEADS>
 int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
-  constexpr int EP = 8, RPB = 4 * (64 / EP);
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
-  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;
-  if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((agg_heads_bwd_dst_kernel<HEADS, EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  BGNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((agg_heads_bwd_src_kernel<HEADS, EP>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  BGNN_LAUNCH_CHECK();
-  return 0;
+  // (EP, U) from a sweep on C4 (tools/heads_bwd_time.py); env override for that sweep only
+  static const int cfg = [] { const char* e = getenv("BGNN_HEADS_BWD_CFG"); return e ? atoi(e) : 0; }();
+#define BGNN_HB(EPV, UV)                                                                                               \
+  do {                                                                                                                 \
+    constexpr int RPB = 4 * (64 / EPV);                                                                                \
+    const int64_t ntiles = (p.N + RPB - 1) / RPB;                                                                      \
+    int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;                                                        \
+    if (grid < 8) grid = 8;                                                                                            \
+    hipLaunchKernelGGL((agg_heads_bwd_dst_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
+    BGNN_LAUNCH_CHECK();                                                                                               \
+    hipLaunchKernelGGL((agg_heads_bwd_src_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
+    BGNN_LAUNCH_CHECK();                                                                                               \
+    return 0;                                                                                                          \
+  } while (0)
+  if (cfg == 81) BGNN_HB(8, 1);
+  if (cfg == 82) BGNN_HB(8, 2);
+  if (cfg == 44) BGNN_HB(4, 4);
+  if (cfg == 41) BGNN_HB(4, 1);
+  BGNN_HB(4, 2);                                 // C4: 8/1 1.45, 8/2 1.42, 4/1 1.38, 4/2 1.33, 4/4 1.33 ms for the two passes
+#undef BGNN_HB
 }
 
 template <int LF>
@@ -780,8 +818,9 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
 }
 
 extern "C" size_t bgnn_aggregate_heads_bwd_workspace_bytes(int64_t N, int64_t E, int32_t heads) {
-  const size_t n = (size_t)(N > 0 ? N : 0), e = (size_t)(E > 0 ? E : 0), h = (size_t)(heads > 0 ? heads : 0);
-  return bgnn_align_up(32 * e, 256) + 2 * bgnn_align_up(sizeof(float) * n * h * 4, 256) + 256;
+  (void)E;                                       // nothing per edge is kept
+  const size_t n = (size_t)(N > 0 ? N : 0), h = (size_t)(heads > 0 ? heads : 0);
+  return bgnn_align_up(sizeof(float4) * n * 3 * h, 256) + bgnn_align_up(sizeof(float) * n * h * 4, 256) + 256;
 }
 
 extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
@@ -791,7 +830,8 @@ extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, cons
                                                         const float* out, const float* state_ms, const float* grad_out,
                                                         int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s,
                                                         float* da_s2t, void* ws, size_t ws_bytes, void* stream) {
-  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_eid || !t_dst || !out || !state_ms ||
+  (void)t_eid;                                   // (kept in the signature: the by-source view is passed as one triple everywhere)
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_dst || !out || !state_ms ||
       !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
     return BGNN_E_NULL;
   if (N < 0 || E < 0 || D < 1 || D > 4 || (heads != 2 && heads != 3)) return BGNN_E_SHAPE;
@@ -800,12 +840,10 @@ extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, cons
     return BGNN_E_ALIGN;
   if (ws_bytes < bgnn_aggregate_heads_bwd_workspace_bytes(N, E, heads)) return BGNN_E_WORKSPACE;
   if (N == 0) return 0;
-  uint4* rec = (uint4*)ws;
-  const size_t tb = bgnn_align_up(sizeof(float) * (size_t)N * (size_t)heads * 4, 256);
-  float* dstside = (float*)((char*)ws + bgnn_align_up((size_t)32 * (size_t)E, 256));
-  float* grbuf = (float*)((char*)dstside + tb);
+  float4* node = (float4*)ws;
+  float* dstside = (float*)((char*)ws + bgnn_align_up(sizeof(float4) * (size_t)N * 3 * (size_t)heads, 256));
   HeadsBwdParams p{h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, state_ms, grad_out, log_softmax,
-                   t_rowptr, t_eid, t_dst, rec, dstside, grbuf, dh_t2s, dh_s2t, da_t2s, da_s2t};
+                   t_rowptr, t_dst, node, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
   hipStream_t st = (hipStream_t)stream;
   return heads == 3 ? launch_heads_bwd<3>(p, st) : launch_heads_bwd<2>(p, st);
 }
