@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
                                                                  int64_t ldg, int D, const uint8_t* __restrict__ mask,
                                                                  const float* __restrict__ gx, const float* __restrict__ gconst,
                                                                  const float* __restrict__ wd, const double* __restrict__ counts,
-                                                                 float* __restrict__ Gall, int p, float* __restrict__ side) {
+                                                                 float* __restrict__ Gall, int p, int64_t ld_gall,
+                                                                 float* __restrict__ side, int64_t ld_side) {
   const int tid = threadIdx.x, l32 = tid & 31;
   const float gc0 = gconst[0], gc1 = gconst[1];
   // column 2D+2 of Gall: d(delta)/d(x_i) = +1/n_S on source rows, -1/n_T on target rows -- the input gradient's term
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
       a0 = fmaf(xv.x, u.x, a0); a0 = fmaf(xv.y, u.y, a0); a0 = fmaf(xv.z, u.z, a0); a0 = fmaf(xv.w, u.w, a0);
       a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
     }
-    float* go = Gall + r * p;
+    float* go = Gall + r * ld_gall;
     for (int c = l32; c < D; c += 32) {
       const float g1 = G_s2t[r * ldg + c], g2 = G_t2s[r * ldg + c];
       d0 = fmaf(g1, wd[c], d0);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
       go[2 * D + 1] = S ? 0.f : d1 * (1.f - g1 * g1);
       go[2 * D + 2] = S ? cS : cT;
       for (int c = 2 * D + 3; c < p; ++c) go[c] = 0.f;
-      *reinterpret_cast<float4*>(side + r * 4) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
+      *reinterpret_cast<float4*>(side + r * ld_side) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
     }
   }
 }
@@ -467,15 +468,18 @@ extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d
 extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t,
                                            const float* G_t2s, int64_t ldg, int32_t D, const uint8_t* mask,
                                            const float* gx, const float* gconst, const float* wd, const double* counts,
-                                           float* Gall, int32_t p, float* side, void* stream) {
+                                           float* Gall, int32_t p, int64_t ld_gall, float* side, int64_t ld_side,
+                                           void* stream) {
   if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !counts || !Gall || !side) return BGNN_E_NULL;
-  if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 3 || (p & 3)) return BGNN_E_SHAPE;
+  if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 3 || (p & 3) || ld_gall < p ||
+      ld_side < 4 || (ld_side & 3))
+    return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || !bgnn_aligned16(side)) return BGNN_E_ALIGN;
   if (N == 0) return 0;
   int64_t grid = (N + 7) / 8;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(transform_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, din, G_s2t,
-                     G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, side);
+                     G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side, ld_side);
   BGNN_LAUNCH_CHECK();
   return 0;
 }

@@ -317,6 +317,74 @@ class _TransformFn(torch.autograd.Function):
         return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None
 
 
+class _TransformPairFn(torch.autograd.Function):
+    """Two convs on the SAME input (clf_base and clf_target on the hidden activation, KTGNN.py:432,:434) as one function: one
+    pass over x forward (the packed pair kernel) and, backward, ONE Gram product, ONE side Gram and ONE input-gradient launch
+    for both (their Gall / side blocks sit side by side in one pair of buffers) -- separately each conv streams x three times,
+    writes its own [N, Din] input gradient and autograd adds the two.  Same hand-derived backward as `_TransformFn`."""
+
+    @staticmethod
+    def supported(x, conv_a, conv_b):
+        din, D = x.shape[1], conv_a.out_channels
+        p2 = 2 * ops.pad4(2 * D + 3)
+        return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and din % 4 == 0 and din <= 128 and D <= 4
+                and conv_b.out_channels == D and x.data_ptr() % 16 == 0 and x.shape[0] >= 4096
+                and ops.gram_supported(p2, din) and ops.linear_supported(p2, din)
+                and all(c.lin_s.bias is not None and c.lin_t.bias is not None for c in (conv_a, conv_b)))
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, conv_a, conv_b, sums, *params):
+        # params: per conv (W_s, b_s, W_t, b_t, ag_s2t, ag_t2s)
+        din = x.shape[1]
+        if sums is None:
+            sums = ops.domain_sums(x, mask_u8)
+        delta = ops.domain_delta(sums, din)
+        (a_t2s, a_s2t), (b_t2s, b_s2t) = conv_a.transform(x, mask_u8, sums=sums, partner=conv_b)
+        ctx.save_for_backward(x, mask_u8, delta, sums, *params)
+        return a_t2s, a_s2t, b_t2s, b_s2t
+
+    @staticmethod
+    def backward(ctx, Ga_t2s, Ga_s2t, Gb_t2s, Gb_s2t):
+        x, mask_u8, delta, sums, *params = ctx.saved_tensors
+        N, din = x.shape
+        dl = delta[:din]
+        counts = sums[-2:].contiguous()
+        convs = []
+        for c, (G_t2s, G_s2t) in enumerate(((Ga_t2s, Ga_s2t), (Gb_t2s, Gb_s2t))):
+            W_s, b_s, W_t, b_t, ag_s2t, ag_t2s = params[6 * c:6 * c + 6]
+            convs.append((W_s, W_t, ag_s2t.reshape(-1), ag_t2s.reshape(-1), G_t2s.contiguous(), G_s2t.contiguous()))
+        D = convs[0][0].shape[0]
+        p = ops.pad4(2 * D + 3)
+        Gall = torch.empty(N, 2 * p, dtype=torch.float32, device=x.device)
+        side = torch.empty(N, 8, dtype=torch.float32, device=x.device)
+        for c, (W_s, W_t, g1, g2, G_t2s, G_s2t) in enumerate(convs):
+            Gx = torch.stack((g1[:din], g2[:din])).contiguous()
+            gconst = torch.stack((dl @ g1[din:], dl @ g2[din:]))
+            wd = x.new_zeros(2, 2 * D)
+            wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
+            ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, counts,
+                                   out=(Gall[:, c * p:(c + 1) * p], side[:, 4 * c:4 * c + 4]))
+        dWall2 = ops.gram(Gall, x)                                              # [2p, Din]
+        ex2 = ops.gram(side, Gall)                                              # [8, 2p]
+        Wcat = x.new_zeros(2 * p, din)
+        grads = []
+        for c, (W_s, W_t, g1, g2, _, _) in enumerate(convs):
+            dWall = dWall2[c * p:(c + 1) * p]
+            ex = ex2[4 * c:4 * c + 4, c * p:(c + 1) * p].t()                    # [p, 4] as in _TransformFn.backward
+            u1, u2 = ex[:D, 0], ex[D:2 * D, 1]
+            sp = ex[2 * D:2 * D + 2, 2]
+            dW_t = dWall[:D] - torch.outer(u1, dl)
+            dW_s = dWall[D:2 * D] + torch.outer(u2, dl)
+            dg1 = torch.cat((dWall[2 * D], sp[0] * dl))
+            dg2 = torch.cat((dWall[2 * D + 1], sp[1] * dl))
+            Wc = Wcat[c * p:(c + 1) * p]
+            Wc[:D], Wc[D:2 * D], Wc[2 * D], Wc[2 * D + 1] = W_t, W_s, g1[:din], g2[:din]
+            Wc[2 * D + 2] = sp[0] * g1[din:] + sp[1] * g2[din:] - W_t.t() @ u1 + W_s.t() @ u2   # through the domain means
+            grads += [dW_s, ex[D:2 * D, 2], dW_t, ex[:D, 2], dg1.reshape(params[6 * c + 4].shape), dg2.reshape(params[6 * c + 5].shape)]
+        dX = ops.linear(Gall, Wcat.t().contiguous(), x.new_zeros(din)) if ctx.needs_input_grad[0] else None
+        return (dX, None, None, None, None, *grads)
+
+
 class AdaptedConv(nn.Module):
     """Reference `AdaptedConv(MessagePassing)` -- models/KTGNN.py:218-328.
 
@@ -671,8 +739,13 @@ class KTGNN_no_complement(nn.Module):
             sums_x = ops.domain_sums(_pad_cols4(x.detach()), mask_u8)
             l0, bn, _, l3 = self.clf_transformer
             xt = l3(bn_relu_dropout_train(l0(x), bn, True, 0.0)).contiguous()
-            tabs = (*self.clf_base._transform_autograd(x, mask_u8, sums_x), *self.clf_target._transform_autograd(x, mask_u8, sums_x),
-                    *self.clf_target._transform_autograd(xt, mask_u8))
+            if _TransformPairFn.supported(x, self.clf_base, self.clf_target):
+                prm = [t for c in (self.clf_base, self.clf_target)
+                       for t in (c.lin_s.weight, c.lin_s.bias, c.lin_t.weight, c.lin_t.bias, c.a_g_s2t.weight, c.a_g_t2s.weight)]
+                tabs_x = _TransformPairFn.apply(x, mask_u8, self.clf_base, self.clf_target, sums_x, *prm)
+            else:
+                tabs_x = (*self.clf_base._transform_autograd(x, mask_u8, sums_x), *self.clf_target._transform_autograd(x, mask_u8, sums_x))
+            tabs = (*tabs_x, *self.clf_target._transform_autograd(xt, mask_u8))
             cs = (self.clf_base, self.clf_target, self.clf_target)
             a_t = torch.stack([c.a_f_t2s.weight.reshape(-1) for c in cs])
             a_s = torch.stack([c.a_f_s2t.weight.reshape(-1) for c in cs])

@@ -139,11 +139,12 @@ int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y, int64_t N,
  *   adjoints G.(W delta) (wd [2][2D]: row 0 = -(W_t delta) in columns 0..D-1, row 1 = W_s delta in columns D..2D-1), and
  *   Gall[N][p] = [G_s2t[:, :D] | G_t2s[:, :D] | dpre_0 dpre_1 | +1/n_S or -1/n_T | 0] (p = pad4(2D+3); counts = the
  *   two node counts at the end of the domain sums), side[N][4] = (c1, c2, 1, 0): the operands of the Gram / linear
- *   launches that follow (column 2D+2 carries the gradient through the domain means as one more rank).  din % 4 == 0. */
+ *   launches that follow (column 2D+2 carries the gradient through the domain means as one more rank).  din % 4 == 0.
+ *   ld_gall >= p / ld_side >= 4 are the row strides: two convs on the same x write side by side into one pair of buffers. */
 int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t, const float* G_t2s,
                                 int64_t ldg, int32_t D, const uint8_t* mask, const float* gx /*[2][din]*/,
                                 const float* gconst /*[2]*/, const float* wd /*[2][2D]*/, const double* counts /*[2]*/,
-                                float* Gall, int32_t p, float* side, void* stream);
+                                float* Gall, int32_t p, int64_t ld_gall, float* side, int64_t ld_side, void* stream);
 /* bgnn_rowdot_f32: out[i][j] = X[i,:d] . V[j,:d], j < nv <= 4, d <= 256 (gate pre-activations and gate adjoints of the
  *   training path): one stream over X for all vectors. */
 int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
