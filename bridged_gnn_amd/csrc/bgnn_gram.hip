@@ -402,20 +402,30 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 //   dpre = (S ? dc_0 (1 - gam_0^2) : 0,  S ? 0 : dc_1 (1 - gam_1^2))
 //   Gall[i] = [G_s2t[i,:D] | G_t2s[i,:D] | dpre_0 dpre_1 | +-1/n_dom | 0...]  (p = pad4(2D+3) columns);  side[i] = (c1, c2, 1, 0)
 // 32 lanes own a row (two rows per wave); element-wise indexing over D so that any D works.
+template <bool EX>
 __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int din,
                                                                  const float* __restrict__ G_s2t, const float* __restrict__ G_t2s,
                                                                  int64_t ldg, int D, const uint8_t* __restrict__ mask,
                                                                  const float* __restrict__ gx, const float* __restrict__ gconst,
                                                                  const float* __restrict__ wd, const double* __restrict__ counts,
                                                                  float* __restrict__ Gall, int p, int64_t ld_gall,
-                                                                 float* __restrict__ side, int64_t ld_side) {
+                                                                 float* __restrict__ side, int64_t ld_side, float* __restrict__ ex_part) {
+  // EX (D <= 128): the N-reductions of Gall against side that the backward needs -- sum_i c1_i G1_i, sum_i c2_i G2_i, the
+  // column sums of G1 / G2 (bias gradients) and sum_i dpre_i -- are accumulated here per lane (a lane owns columns
+  // l32 + 32k of its rows), reduced over the block in a fixed order and written as one partial [p][4] per block: Gall is
+  // not streamed a second time by a side Gram.  Layout of a partial = the entries of ex = Gall^T side that are used.
+  extern __shared__ float exs[];                 // EX: [8 row groups][p * 4]
+  constexpr int MAXK = 4;
   const int tid = threadIdx.x, l32 = tid & 31;
   const float gc0 = gconst[0], gc1 = gconst[1];
   // column 2D+2 of Gall: d(delta)/d(x_i) = +1/n_S on source rows, -1/n_T on target rows -- the input gradient's term
   // through the domain means is then one more rank of the Gall . Wcat product instead of an [N,Din] multiply + add
   const float cS = (float)(1.0 / counts[0]), cT = (float)(-1.0 / counts[1]);
+  float eu1[MAXK], eb1[MAXK], eu2[MAXK], eb2[MAXK], es0 = 0.f, es1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) eu1[k] = eb1[k] = eu2[k] = eb2[k] = 0.f;
   const int64_t rows_per_pass = (int64_t)gridDim.x * 8;             // 8 rows per block and pass
-  for (int64_t r = (int64_t)blockIdx.x * 8 + (tid >> 5); r < N; r += rows_per_pass) {
+  auto do_row = [&](int64_t r) {
     float a0 = 0.f, a1 = 0.f, d0 = 0.f, d1 = 0.f;
     for (int k = l32 * 4; k < din; k += 128) {                      // din % 4 == 0 (host)
       const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + k);
@@ -424,22 +434,75 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
       a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
     }
     float* go = Gall + r * ld_gall;
-    for (int c = l32; c < D; c += 32) {
-      const float g1 = G_s2t[r * ldg + c], g2 = G_t2s[r * ldg + c];
-      d0 = fmaf(g1, wd[c], d0);
-      d1 = fmaf(g2, wd[2 * D + D + c], d1);
-      go[c] = g1; go[D + c] = g2;
+    float g1v[MAXK], g2v[MAXK];
+    if constexpr (EX) {
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = l32 + 32 * k;
+        g1v[k] = g2v[k] = 0.f;
+        if (c < D) {
+          g1v[k] = G_s2t[r * ldg + c]; g2v[k] = G_t2s[r * ldg + c];
+          d0 = fmaf(g1v[k], wd[c], d0);
+          d1 = fmaf(g2v[k], wd[2 * D + D + c], d1);
+          go[c] = g1v[k]; go[D + c] = g2v[k];
+        }
+      }
+    } else {
+      for (int c = l32; c < D; c += 32) {
+        const float g1 = G_s2t[r * ldg + c], g2 = G_t2s[r * ldg + c];
+        d0 = fmaf(g1, wd[c], d0);
+        d1 = fmaf(g2, wd[2 * D + D + c], d1);
+        go[c] = g1; go[D + c] = g2;
+      }
     }
     a0 = bgnn::group_sum<32>(a0); a1 = bgnn::group_sum<32>(a1);
     d0 = bgnn::group_sum<32>(d0); d1 = bgnn::group_sum<32>(d1);
+    const bool S = mask[r] != 0;
+    float g0 = 0.f, g1 = 0.f;
+    if (l32 == 0) { g0 = tanhf(a0 + gc0); g1 = tanhf(a1 + gc1); }
+    if constexpr (EX) {                          // the gate values reach the row's other lanes for the reductions below
+      g0 = __shfl(g0, threadIdx.x & 32); g1 = __shfl(g1, threadIdx.x & 32);
+      const float c1 = S ? g0 : 0.f, c2 = S ? 0.f : g1;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        eu1[k] = fmaf(c1, g1v[k], eu1[k]); eb1[k] += g1v[k];
+        eu2[k] = fmaf(c2, g2v[k], eu2[k]); eb2[k] += g2v[k];
+      }
+    }
     if (l32 == 0) {
-      const bool S = mask[r] != 0;
-      const float g0 = tanhf(a0 + gc0), g1 = tanhf(a1 + gc1);
-      go[2 * D] = S ? d0 * (1.f - g0 * g0) : 0.f;
-      go[2 * D + 1] = S ? 0.f : d1 * (1.f - g1 * g1);
+      const float dp0 = S ? d0 * (1.f - g0 * g0) : 0.f, dp1 = S ? 0.f : d1 * (1.f - g1 * g1);
+      go[2 * D] = dp0;
+      go[2 * D + 1] = dp1;
       go[2 * D + 2] = S ? cS : cT;
       for (int c = 2 * D + 3; c < p; ++c) go[c] = 0.f;
-      *reinterpret_cast<float4*>(side + r * ld_side) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
+      if (side != nullptr) *reinterpret_cast<float4*>(side + r * ld_side) = make_float4(S ? g0 : 0.f, S ? 0.f : g1, 1.f, 0.f);
+      es0 += dp0; es1 += dp1;
+    }
+  };
+  // two rows per 32-lane group in flight (EX runs a smaller grid -- one partial per block -- so each wave carries more)
+  int64_t r = (int64_t)blockIdx.x * 8 + (tid >> 5);
+  for (; r + rows_per_pass < N; r += 2 * rows_per_pass) { do_row(r); do_row(r + rows_per_pass); }
+  if (r < N) do_row(r);
+  if constexpr (EX) {
+    const int P4 = p * 4, gi = tid >> 5;
+    for (int t = tid; t < 8 * P4; t += 256) exs[t] = 0.f;
+    __syncthreads();
+    float* mine = exs + gi * P4;                 // every (column, slot) of a group's copy has exactly one owner lane
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = l32 + 32 * k;
+      if (c < D) {
+        mine[c * 4 + 0] = eu1[k]; mine[c * 4 + 2] = eb1[k];
+        mine[(D + c) * 4 + 1] = eu2[k]; mine[(D + c) * 4 + 2] = eb2[k];
+      }
+    }
+    if (l32 == 0) { mine[(2 * D) * 4 + 2] = es0; mine[(2 * D + 1) * 4 + 2] = es1; }
+    __syncthreads();
+    for (int t = tid; t < P4; t += 256) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += exs[q * P4 + t];
+      ex_part[(int64_t)blockIdx.x * P4 + t] = sum;
     }
   }
 }
@@ -465,21 +528,74 @@ extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d
   return 0;
 }
 
+// out[e] = sum over the per-block partials part[b][e] in a fixed order (deterministic): 64 consecutive elements per block
+// (coalesced 256-byte reads), 16 groups of threads take the partials round-robin, 8 loads in flight each
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ part, int nblk, int64_t pq, float* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
+  double s = 0.0;
+  if (e < pq) {
+    int b = grp;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 16 * u) * pq + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nblk; b += 16) s += (double)part[(int64_t)b * pq + e];
+  }
+  red[grp][el] = s;
+  __syncthreads();
+  if (grp == 0 && e < pq) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][el];
+    out[e] = (float)t;
+  }
+}
+
+static int prep_blocks(int64_t N, bool ex) {
+  int64_t grid = (N + 7) / 8;
+  const int64_t cap = ex ? 2048 : 8192;          // EX: one [p][4] partial per block
+  if (grid > cap) grid = cap;
+  return grid < 1 ? 1 : (int)grid;
+}
+
+extern "C" size_t bgnn_transform_bwd_prep_workspace_bytes(int64_t N, int32_t p) {
+  return sizeof(float) * (size_t)prep_blocks(N > 0 ? N : 0, true) * (size_t)(p > 0 ? p : 0) * 4 + 256;
+}
+
 extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t,
                                            const float* G_t2s, int64_t ldg, int32_t D, const uint8_t* mask,
                                            const float* gx, const float* gconst, const float* wd, const double* counts,
-                                           float* Gall, int32_t p, int64_t ld_gall, float* side, int64_t ld_side,
-                                           void* stream) {
-  if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !counts || !Gall || !side) return BGNN_E_NULL;
+                                           float* Gall, int32_t p, int64_t ld_gall, float* side_opt, int64_t ld_side,
+                                           float* ex_opt, void* ws_opt, size_t ws_bytes, void* stream) {
+  if (!x || !G_s2t || !G_t2s || !mask || !gx || !gconst || !wd || !counts || !Gall || (!side_opt && !ex_opt)) return BGNN_E_NULL;
   if (N < 0 || din <= 0 || (din & 3) || (ldx & 3) || ldx < din || D <= 0 || ldg < D || p < 2 * D + 3 || (p & 3) || ld_gall < p ||
-      ld_side < 4 || (ld_side & 3))
+      (side_opt && (ld_side < 4 || (ld_side & 3))))
     return BGNN_E_SHAPE;
-  if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || !bgnn_aligned16(side)) return BGNN_E_ALIGN;
-  if (N == 0) return 0;
-  int64_t grid = (N + 7) / 8;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(transform_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, din, G_s2t,
-                     G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side, ld_side);
+  if (ex_opt && (D > 128 || !ws_opt)) return ex_opt && D > 128 ? BGNN_E_SHAPE : BGNN_E_NULL;
+  if (ex_opt && ws_bytes < bgnn_transform_bwd_prep_workspace_bytes(N, p)) return BGNN_E_WORKSPACE;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || (side_opt && !bgnn_aligned16(side_opt))) return BGNN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) {
+    if (ex_opt && hipMemsetAsync(ex_opt, 0, sizeof(float) * 4 * (size_t)p, st) != hipSuccess) return (int)hipErrorInvalidValue;
+    return 0;
+  }
+  const int grid = prep_blocks(N, ex_opt != nullptr);
+  if (ex_opt) {
+    hipLaunchKernelGGL(transform_bwd_prep_kernel<true>, dim3((unsigned)grid), dim3(256), sizeof(float) * 8 * 4 * (size_t)p, st, x,
+                       ldx, N, din, G_s2t, G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side,
+                       (float*)ws_opt);
+    BGNN_LAUNCH_CHECK();
+    const int64_t pq = (int64_t)p * 4;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((pq + 63) / 64)), dim3(1024), 0, st, (const float*)ws_opt, grid, pq, ex_opt);
+  } else {
+    hipLaunchKernelGGL(transform_bwd_prep_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, x, ldx, N, din, G_s2t,
+                       G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side, (float*)nullptr);
+  }
   BGNN_LAUNCH_CHECK();
   return 0;
 }

@@ -271,10 +271,15 @@ class _TransformFn(torch.autograd.Function):
         fused_prep = (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
                       and G_s2t.stride(0) == G_t2s.stride(0))
         p = ops.pad4(2 * D + 3) if fused_prep else ops.pad4(2 * D + 2)
+        ex = None
         if fused_prep:
             # row-local part in ONE stream over x and the two gradient tables (gate values, their adjoints, Gall, side);
-            # column 2D+2 of Gall = +1/n_S | -1/n_T carries the gradient through the domain means (see dX below)
-            Gall, side = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, sums[-2:].contiguous())
+            # column 2D+2 of Gall = +1/n_S | -1/n_T carries the gradient through the domain means (see dX below).
+            # D <= 128: the same pass also reduces Gall against side (ex below) -- no second stream over Gall
+            if D <= 128:
+                Gall, ex = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, sums[-2:].contiguous(), want_ex=True)
+            else:
+                Gall, side = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, sums[-2:].contiguous())
         else:
             pre = x @ Gx.t() + gconst
             gam = torch.tanh(pre)
@@ -290,7 +295,10 @@ class _TransformFn(torch.autograd.Function):
             side = torch.stack((c1, c2, torch.ones_like(c1), torch.zeros_like(c1)), dim=1)   # [N, 4]
         if fast and ops.gram_supported(p, din):
             dWall = ops.gram(Gall, x)                                            # [p, Din]  streaming Gram kernel
-            ex = torch.cat([ops.gram(side, Gall[:, c0:min(c0 + 128, p)]) for c0 in range(0, p, 128)], dim=1).t()   # [p, 4]
+            if ex is None:
+                ex = torch.cat([ops.gram(side, Gall[:, c0:min(c0 + 128, p)]) for c0 in range(0, p, 128)], dim=1).t()   # [p, 4]
+        elif ex is not None:
+            dWall = Gall.t() @ x
         else:
             dWall, ex = Gall.t() @ x, Gall.t() @ side
         u1, u2 = ex[:D, 0], ex[D:2 * D, 1]                                      # sum_i gate_i G_i
@@ -356,21 +364,20 @@ class _TransformPairFn(torch.autograd.Function):
         D = convs[0][0].shape[0]
         p = ops.pad4(2 * D + 3)
         Gall = torch.empty(N, 2 * p, dtype=torch.float32, device=x.device)
-        side = torch.empty(N, 8, dtype=torch.float32, device=x.device)
+        exs = []
         for c, (W_s, W_t, g1, g2, G_t2s, G_s2t) in enumerate(convs):
             Gx = torch.stack((g1[:din], g2[:din])).contiguous()
             gconst = torch.stack((dl @ g1[din:], dl @ g2[din:]))
             wd = x.new_zeros(2, 2 * D)
             wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
-            ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, counts,
-                                   out=(Gall[:, c * p:(c + 1) * p], side[:, 4 * c:4 * c + 4]))
+            exs.append(ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, counts,
+                                              out=(Gall[:, c * p:(c + 1) * p], None), want_ex=True)[1])
         dWall2 = ops.gram(Gall, x)                                              # [2p, Din]
-        ex2 = ops.gram(side, Gall)                                              # [8, 2p]
         Wcat = x.new_zeros(2 * p, din)
         grads = []
         for c, (W_s, W_t, g1, g2, _, _) in enumerate(convs):
             dWall = dWall2[c * p:(c + 1) * p]
-            ex = ex2[4 * c:4 * c + 4, c * p:(c + 1) * p].t()                    # [p, 4] as in _TransformFn.backward
+            ex = exs[c]                                                         # [p, 4] as in _TransformFn.backward
             u1, u2 = ex[:D, 0], ex[D:2 * D, 1]
             sp = ex[2 * D:2 * D + 2, 2]
             dW_t = dWall[:D] - torch.outer(u1, dl)

@@ -168,26 +168,35 @@ def narrow_transform_finish(raw, mask_u8, sums, packed, out):
     return out
 
 
-def transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, gx, gconst, wd, counts, out=None):
+def transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, gx, gconst, wd, counts, out=None, want_ex=False):
     """-> (Gall [N, pad4(2D+3)], side [N, 4]): the row-local part of the transform backward in one pass (see bgnn.h);
-    `counts` = float64 [2] (n_S, n_T), e.g. the tail of the domain sums.  `out` = (Gall view, side view): column slices of
-    wider buffers when several convs on the same x share the launches that follow."""
+    `counts` = float64 [2] (n_S, n_T), e.g. the tail of the domain sums.  `out` = (Gall view, side view or None): column
+    slices of wider buffers when several convs on the same x share the launches that follow.
+    want_ex (D <= 128): -> (Gall, ex [p, 4]) instead -- the used entries of Gall^T side from the same pass, no side buffer."""
     N, din = x.shape
     p = pad4(2 * D + 3)
     assert counts.dtype == torch.float64 and counts.numel() == 2
     if out is None:
         Gall = torch.empty(N, p, dtype=torch.float32, device=x.device)
-        side = torch.empty(N, 4, dtype=torch.float32, device=x.device)
+        side = None if want_ex else torch.empty(N, 4, dtype=torch.float32, device=x.device)
     else:
         Gall, side = out
-        assert Gall.shape == (N, p) and side.shape == (N, 4)
+        assert Gall.shape == (N, p) and (side is None or side.shape == (N, 4))
     assert G_s2t.stride(0) == G_t2s.stride(0) and G_s2t.stride(1) == 1 and G_t2s.stride(1) == 1
-    rc = L.lib().bgnn_transform_bwd_prep_f32(L.ptr_rows(x), x.stride(0), N, din, L.ptr_rows(G_s2t), L.ptr_rows(G_t2s),
-                                             G_s2t.stride(0), D, L.ptr(mask_u8), L.ptr(gx), L.ptr(gconst), L.ptr(wd),
-                                             L.ptr(counts), L.ptr_rows(Gall), p, Gall.stride(0), L.ptr_rows(side), side.stride(0),
-                                             L.stream())
+    lib = L.lib()
+    ex = ws = None
+    wsb = 0
+    if want_ex:
+        ex = torch.empty(p, 4, dtype=torch.float32, device=x.device)
+        wsb = lib.bgnn_transform_bwd_prep_workspace_bytes(N, p)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = lib.bgnn_transform_bwd_prep_f32(L.ptr_rows(x), x.stride(0), N, din, L.ptr_rows(G_s2t), L.ptr_rows(G_t2s),
+                                         G_s2t.stride(0), D, L.ptr(mask_u8), L.ptr(gx), L.ptr(gconst), L.ptr(wd),
+                                         L.ptr(counts), L.ptr_rows(Gall), p, Gall.stride(0),
+                                         L.ptr_rows(side) if side is not None else None, side.stride(0) if side is not None else 4,
+                                         L.ptr(ex), L.ptr(ws), wsb, L.stream())
     L.check(rc, "bgnn_transform_bwd_prep_f32")
-    return Gall, side
+    return (Gall, ex) if want_ex else (Gall, side)
 
 
 def gram_supported(p, q):

@@ -140,11 +140,16 @@ int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y, int64_t N,
  *   Gall[N][p] = [G_s2t[:, :D] | G_t2s[:, :D] | dpre_0 dpre_1 | +1/n_S or -1/n_T | 0] (p = pad4(2D+3); counts = the
  *   two node counts at the end of the domain sums), side[N][4] = (c1, c2, 1, 0): the operands of the Gram / linear
  *   launches that follow (column 2D+2 carries the gradient through the domain means as one more rank).  din % 4 == 0.
- *   ld_gall >= p / ld_side >= 4 are the row strides: two convs on the same x write side by side into one pair of buffers. */
+ *   ld_gall >= p / ld_side >= 4 are the row strides: two convs on the same x write side by side into one pair of buffers.
+ *   ex_opt (D <= 128; ws: bgnn_transform_bwd_prep_workspace_bytes(N, p)): the entries of ex = Gall^T side that the backward uses
+ *   (ex[c][0] = sum_i c1_i G_s2t[i][c], ex[D+c][1] = sum_i c2_i G_t2s[i][c], ex[.][2] = column sums of G_s2t | G_t2s | dpre; all
+ *   other entries 0) from the same pass -- per-block partials summed in a fixed order, deterministic; side_opt may then be NULL. */
+size_t bgnn_transform_bwd_prep_workspace_bytes(int64_t N, int32_t p);
 int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t, const float* G_t2s,
                                 int64_t ldg, int32_t D, const uint8_t* mask, const float* gx /*[2][din]*/,
                                 const float* gconst /*[2]*/, const float* wd /*[2][2D]*/, const double* counts /*[2]*/,
-                                float* Gall, int32_t p, int64_t ld_gall, float* side, int64_t ld_side, void* stream);
+                                float* Gall, int32_t p, int64_t ld_gall, float* side_opt, int64_t ld_side,
+                                float* ex_opt /*[p][4]*/, void* ws_opt, size_t ws_bytes, void* stream);
 /* bgnn_rowdot_f32: out[i][j] = X[i,:d] . V[j,:d], j < nv <= 4, d <= 256 (gate pre-activations and gate adjoints of the
  *   training path): one stream over X for all vectors. */
 int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,

@@ -192,6 +192,15 @@ def test_transform_bwd_prep_matches_torch_formula(din, D, n):
     assert torch.equal(Gall[:, :2 * D].double(), cat)
     assert torch.allclose(Gall.double(), want, rtol=1e-5, atol=1e-5 * float(dc.abs().max()))
     assert torch.allclose(side.double(), want_side, rtol=1e-5, atol=2e-6)
+    if D <= 128:
+        # want_ex: the used entries of Gall^T side from the same pass (u1, u2, bias sums, sum dpre), deterministic
+        Gall2, ex = ops.transform_bwd_prep(x, G1, G2, D, m.to(torch.uint8), gx, gconst, wd, counts, want_ex=True)
+        assert torch.equal(Gall2, Gall)
+        full = want.t() @ want_side                                              # [p, 4] in fp64
+        ref = torch.zeros_like(full)
+        ref[:D, 0], ref[D:2 * D, 1], ref[:2 * D + 2, 2] = full[:D, 0], full[D:2 * D, 1], full[:2 * D + 2, 2]
+        assert torch.allclose(ex.double(), ref, rtol=1e-4, atol=2e-5 * float(full.abs().max())), float((ex.double() - ref).abs().max())
+        assert torch.equal(ops.transform_bwd_prep(x, G1, G2, D, m.to(torch.uint8), gx, gconst, wd, counts, want_ex=True)[1], ex)
 
 
 @pytest.mark.parametrize("n,d,relu,p", [(5000, 128, True, 0.0), (3001, 64, True, 0.5), (777, 100, False, 0.25), (4097, 8, True, 0.0)])
