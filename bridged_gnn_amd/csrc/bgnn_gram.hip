@@ -507,6 +507,80 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
   }
 }
 
+// The O(D x Din) algebra around the streaming launches of the transform backward (ktgnn.py: _TransformFn.backward), as two
+// one-launch kernels instead of ~40 torch element-wise / BLAS-1 launches per conv (each ~5 us on an idle GPU: 0.8 ms of a
+// 15 ms training step for KT-GNN's four convs).
+// consts: gx = [g1_x; g2_x], gconst = (delta . g1_d, delta . g2_d), wd = [-(W_t delta) | 0 ; 0 | W_s delta]
+__global__ __launch_bounds__(256) void transform_bwd_consts_kernel(const float* __restrict__ W_s, const float* __restrict__ W_t,
+                                                                   const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                   const float* __restrict__ delta, int D, int din,
+                                                                   float* __restrict__ gx, float* __restrict__ gconst,
+                                                                   float* __restrict__ wd) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < din; k += 256) { gx[k] = g1[k]; gx[din + k] = g2[k]; }
+  for (int t = tid; t < 4 * D; t += 256) wd[t] = 0.f;
+  __syncthreads();
+  for (int row = wave; row < 2 * D + 2; row += 4) {   // one wave per dot product of length din
+    const float* v = row < D ? W_t + (int64_t)row * din : row < 2 * D ? W_s + (int64_t)(row - D) * din
+                     : row == 2 * D ? g1 + din : g2 + din;
+    float a = 0.f;
+    for (int k = lane; k < din; k += 64) a = fmaf(v[k], delta[k], a);
+    a = bgnn::group_sum<64>(a);
+    if (lane == 0) {
+      if (row < D) wd[row] = -a;
+      else if (row < 2 * D) wd[2 * D + row] = a;      // wd[1][D + c]
+      else gconst[row - 2 * D] = a;
+    }
+  }
+}
+
+// finish: from dWall = Gall^T x [p][din] and ex [p][4] (u1 = ex[:D,0], u2 = ex[D:2D,1], sp = ex[2D:2D+2,2], bias sums ex[:,2]):
+//   dW_t = dWall[:D] - u1 (x) delta,  dW_s = dWall[D:2D] + u2 (x) delta,  dg = [dWall[2D+g] | sp_g delta],  db_* = ex[.][2],
+//   ddl = sp_0 g1_d + sp_1 g2_d - W_t^T u1 + W_s^T u2  (gradient through the domain means), and the operand of the
+//   input-gradient launch, written transposed: wcat_t[k][r] = (W_t | W_s | g1_x | g2_x | ddl | 0)[r][k].
+__global__ __launch_bounds__(128) void transform_bwd_finish_kernel(const float* __restrict__ dWall, const float* __restrict__ ex,
+                                                                   const float* __restrict__ W_s, const float* __restrict__ W_t,
+                                                                   const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                   const float* __restrict__ delta, int D, int din, int p,
+                                                                   float* __restrict__ dW_s, float* __restrict__ dW_t,
+                                                                   float* __restrict__ dg1, float* __restrict__ dg2,
+                                                                   float* __restrict__ db_s, float* __restrict__ db_t,
+                                                                   float* __restrict__ wcat_t, int64_t ld_wcat) {
+  const int r = blockIdx.x;                       // row of Wcat / dWall
+  const float sp0 = ex[(2 * D) * 4 + 2], sp1 = ex[(2 * D + 1) * 4 + 2];
+  if (threadIdx.x == 0) {
+    if (r < D) { if (db_t) db_t[r] = ex[r * 4 + 2]; }
+    else if (r < 2 * D) { if (db_s) db_s[r - D] = ex[r * 4 + 2]; }
+  }
+  for (int k = threadIdx.x; k < din; k += 128) {
+    float w;
+    if (r < D) {
+      dW_t[(int64_t)r * din + k] = dWall[(int64_t)r * din + k] - ex[r * 4 + 0] * delta[k];
+      w = W_t[(int64_t)r * din + k];
+    } else if (r < 2 * D) {
+      const int c = r - D;
+      dW_s[(int64_t)c * din + k] = dWall[(int64_t)r * din + k] + ex[r * 4 + 1] * delta[k];
+      w = W_s[(int64_t)c * din + k];
+    } else if (r == 2 * D) {
+      dg1[k] = dWall[(int64_t)r * din + k]; dg1[din + k] = sp0 * delta[k];
+      w = g1[k];
+    } else if (r == 2 * D + 1) {
+      dg2[k] = dWall[(int64_t)r * din + k]; dg2[din + k] = sp1 * delta[k];
+      w = g2[k];
+    } else if (r == 2 * D + 2) {
+      float a = sp0 * g1[din + k] + sp1 * g2[din + k];
+      for (int c = 0; c < D; ++c) {
+        a = fmaf(-W_t[(int64_t)c * din + k], ex[c * 4 + 0], a);
+        a = fmaf(W_s[(int64_t)c * din + k], ex[(D + c) * 4 + 1], a);
+      }
+      w = a;
+    } else {
+      w = 0.f;
+    }
+    wcat_t[(int64_t)k * ld_wcat + r] = w;
+  }
+}
+
 }  // namespace
 
 extern "C" int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
@@ -596,6 +670,29 @@ extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t 
     hipLaunchKernelGGL(transform_bwd_prep_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, x, ldx, N, din, G_s2t,
                        G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side, (float*)nullptr);
   }
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bgnn_transform_bwd_consts_f32(const float* W_s, const float* W_t, const float* g1, const float* g2,
+                                             const float* delta, int32_t D, int32_t din, float* gx, float* gconst, float* wd,
+                                             void* stream) {
+  if (!W_s || !W_t || !g1 || !g2 || !delta || !gx || !gconst || !wd) return BGNN_E_NULL;
+  if (D <= 0 || din <= 0) return BGNN_E_SHAPE;
+  hipLaunchKernelGGL(transform_bwd_consts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, W_s, W_t, g1, g2, delta, D, din,
+                     gx, gconst, wd);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bgnn_transform_bwd_finish_f32(const float* dWall, const float* ex, const float* W_s, const float* W_t,
+                                             const float* g1, const float* g2, const float* delta, int32_t D, int32_t din,
+                                             int32_t p, float* dW_s, float* dW_t, float* dg1, float* dg2, float* db_s_opt,
+                                             float* db_t_opt, float* wcat_t, int64_t ld_wcat, void* stream) {
+  if (!dWall || !ex || !W_s || !W_t || !g1 || !g2 || !delta || !dW_s || !dW_t || !dg1 || !dg2 || !wcat_t) return BGNN_E_NULL;
+  if (D <= 0 || din <= 0 || p < 2 * D + 3 || ld_wcat < p) return BGNN_E_SHAPE;
+  hipLaunchKernelGGL(transform_bwd_finish_kernel, dim3((unsigned)p), dim3(128), 0, (hipStream_t)stream, dWall, ex, W_s, W_t, g1,
+                     g2, delta, D, din, p, dW_s, dW_t, dg1, dg2, db_s_opt, db_t_opt, wcat_t, ld_wcat);
   BGNN_LAUNCH_CHECK();
   return 0;
 }

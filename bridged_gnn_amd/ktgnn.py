@@ -256,11 +256,27 @@ class _TransformFn(torch.autograd.Function):
         x, W_s, W_t, ag_s2t, ag_t2s, mask_u8, delta, sums = ctx.saved_tensors
         N, din = x.shape
         D = W_s.shape[0]
+        g1, g2 = ag_s2t.reshape(-1), ag_t2s.reshape(-1)
+        fast = x.stride(1) == 1 and x.stride(0) % 4 == 0 and din % 4 == 0 and x.data_ptr() % 16 == 0 and din <= 128 and D <= 128
+        p3 = ops.pad4(2 * D + 3)
+        if (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
+                and G_s2t.stride(0) == G_t2s.stride(0) and ops.gram_supported(p3, din)
+                and (not ctx.needs_input_grad[0] or ops.linear_supported(p3, din))):
+            # streaming form: six launches -- small operands, row-local prep (+ the side reductions), Gram, the O(D x Din)
+            # algebra, input gradient (see the torch form below for the formulas)
+            Ws, Wt = W_s.detach().contiguous(), W_t.detach().contiguous()
+            g1c, g2c = g1.detach().contiguous(), g2.detach().contiguous()
+            Gx, gconst, wd = ops.transform_bwd_consts(Ws, Wt, g1c, g2c, delta, din)
+            Gall, ex = ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, sums[-2:].contiguous(), want_ex=True)
+            dWall = ops.gram(Gall, x)
+            wcat_t = torch.empty(din, p3, dtype=torch.float32, device=x.device)
+            dW_s, dW_t, dg1, dg2, db_s, db_t = ops.transform_bwd_finish(dWall, ex, Ws, Wt, g1c, g2c, delta, din, wcat_t)
+            dX = ops.linear(Gall, wcat_t, x.new_zeros(din)) if ctx.needs_input_grad[0] else None
+            return (dX, dW_s, db_s if ctx.has_bias[0] else None, dW_t, db_t if ctx.has_bias[1] else None,
+                    dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None)
         m = mask_u8.bool()
         dl = delta[:din]
         n_s, n_t = sums[-2].float(), sums[-1].float()
-        g1, g2 = ag_s2t.reshape(-1), ag_t2s.reshape(-1)
-        fast = x.stride(1) == 1 and x.stride(0) % 4 == 0 and din % 4 == 0 and x.data_ptr() % 16 == 0 and din <= 128 and D <= 128
         # gate pre-activations: ONE stream over x for both gates (the library needs a 0.5 ms GEMV per vector, or a 2 ms
         # GEMM with a 16-row macro tile for the [N,Din]x[Din,2] product)
         Gx = torch.stack((g1[:din], g2[:din])).contiguous()                      # [2, Din]
@@ -360,35 +376,24 @@ class _TransformPairFn(torch.autograd.Function):
         convs = []
         for c, (G_t2s, G_s2t) in enumerate(((Ga_t2s, Ga_s2t), (Gb_t2s, Gb_s2t))):
             W_s, b_s, W_t, b_t, ag_s2t, ag_t2s = params[6 * c:6 * c + 6]
-            convs.append((W_s, W_t, ag_s2t.reshape(-1), ag_t2s.reshape(-1), G_t2s.contiguous(), G_s2t.contiguous()))
+            convs.append((W_s.detach().contiguous(), W_t.detach().contiguous(), ag_s2t.detach().reshape(-1).contiguous(),
+                          ag_t2s.detach().reshape(-1).contiguous(), G_t2s.contiguous(), G_s2t.contiguous()))
         D = convs[0][0].shape[0]
         p = ops.pad4(2 * D + 3)
         Gall = torch.empty(N, 2 * p, dtype=torch.float32, device=x.device)
         exs = []
         for c, (W_s, W_t, g1, g2, G_t2s, G_s2t) in enumerate(convs):
-            Gx = torch.stack((g1[:din], g2[:din])).contiguous()
-            gconst = torch.stack((dl @ g1[din:], dl @ g2[din:]))
-            wd = x.new_zeros(2, 2 * D)
-            wd[0, :D], wd[1, D:] = -(W_t @ dl), W_s @ dl
+            Gx, gconst, wd = ops.transform_bwd_consts(W_s, W_t, g1, g2, delta, din)
             exs.append(ops.transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, Gx, gconst, wd, counts,
                                               out=(Gall[:, c * p:(c + 1) * p], None), want_ex=True)[1])
         dWall2 = ops.gram(Gall, x)                                              # [2p, Din]
-        Wcat = x.new_zeros(2 * p, din)
+        wcat_t = torch.empty(din, 2 * p, dtype=torch.float32, device=x.device)  # = Wcat^T of both convs side by side
         grads = []
         for c, (W_s, W_t, g1, g2, _, _) in enumerate(convs):
-            dWall = dWall2[c * p:(c + 1) * p]
-            ex = exs[c]                                                         # [p, 4] as in _TransformFn.backward
-            u1, u2 = ex[:D, 0], ex[D:2 * D, 1]
-            sp = ex[2 * D:2 * D + 2, 2]
-            dW_t = dWall[:D] - torch.outer(u1, dl)
-            dW_s = dWall[D:2 * D] + torch.outer(u2, dl)
-            dg1 = torch.cat((dWall[2 * D], sp[0] * dl))
-            dg2 = torch.cat((dWall[2 * D + 1], sp[1] * dl))
-            Wc = Wcat[c * p:(c + 1) * p]
-            Wc[:D], Wc[D:2 * D], Wc[2 * D], Wc[2 * D + 1] = W_t, W_s, g1[:din], g2[:din]
-            Wc[2 * D + 2] = sp[0] * g1[din:] + sp[1] * g2[din:] - W_t.t() @ u1 + W_s.t() @ u2   # through the domain means
-            grads += [dW_s, ex[D:2 * D, 2], dW_t, ex[:D, 2], dg1.reshape(params[6 * c + 4].shape), dg2.reshape(params[6 * c + 5].shape)]
-        dX = ops.linear(Gall, Wcat.t().contiguous(), x.new_zeros(din)) if ctx.needs_input_grad[0] else None
+            dW_s, dW_t, dg1, dg2, db_s, db_t = ops.transform_bwd_finish(dWall2[c * p:(c + 1) * p], exs[c], W_s, W_t, g1, g2, delta,
+                                                                        din, wcat_t[:, c * p:(c + 1) * p])
+            grads += [dW_s, db_s, dW_t, db_t, dg1.reshape(params[6 * c + 4].shape), dg2.reshape(params[6 * c + 5].shape)]
+        dX = ops.linear(Gall, wcat_t, x.new_zeros(din)) if ctx.needs_input_grad[0] else None
         return (dX, None, None, None, None, *grads)
 
 

@@ -199,6 +199,35 @@ def transform_bwd_prep(x, G_s2t, G_t2s, D, mask_u8, gx, gconst, wd, counts, out=
     return (Gall, ex) if want_ex else (Gall, side)
 
 
+def transform_bwd_consts(W_s, W_t, g1, g2, delta, din):
+    """-> (gx [2, din], gconst [2], wd [2, 2D]): the small operands of `transform_bwd_prep` in one launch (see bgnn.h)."""
+    D = W_s.shape[0]
+    dev = W_s.device
+    gx = torch.empty(2, din, dtype=torch.float32, device=dev)
+    gconst = torch.empty(2, dtype=torch.float32, device=dev)
+    wd = torch.empty(2, 2 * D, dtype=torch.float32, device=dev)
+    rc = L.lib().bgnn_transform_bwd_consts_f32(L.ptr(W_s), L.ptr(W_t), L.ptr(g1), L.ptr(g2), L.ptr(delta), D, din,
+                                               L.ptr(gx), L.ptr(gconst), L.ptr(wd), L.stream())
+    L.check(rc, "bgnn_transform_bwd_consts_f32")
+    return gx, gconst, wd
+
+
+def transform_bwd_finish(dWall, ex, W_s, W_t, g1, g2, delta, din, wcat_t):
+    """-> (dW_s, dW_t, dg1 [2 din], dg2 [2 din], db_s, db_t); fills wcat_t ([din, p] view, unit column stride): see bgnn.h."""
+    D = W_s.shape[0]
+    p = dWall.shape[0]
+    dev = W_s.device
+    dW_s, dW_t = torch.empty(D, din, dtype=torch.float32, device=dev), torch.empty(D, din, dtype=torch.float32, device=dev)
+    dg1, dg2 = torch.empty(2 * din, dtype=torch.float32, device=dev), torch.empty(2 * din, dtype=torch.float32, device=dev)
+    db_s, db_t = torch.empty(D, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)
+    assert dWall.is_contiguous() and ex.is_contiguous() and wcat_t.shape == (din, p) and wcat_t.stride(1) == 1
+    rc = L.lib().bgnn_transform_bwd_finish_f32(L.ptr(dWall), L.ptr(ex), L.ptr(W_s), L.ptr(W_t), L.ptr(g1), L.ptr(g2), L.ptr(delta),
+                                               D, din, p, L.ptr(dW_s), L.ptr(dW_t), L.ptr(dg1), L.ptr(dg2), L.ptr(db_s), L.ptr(db_t),
+                                               L.ptr_rows(wcat_t), wcat_t.stride(0), L.stream())
+    L.check(rc, "bgnn_transform_bwd_finish_f32")
+    return dW_s, dW_t, dg1, dg2, db_s, db_t
+
+
 def gram_supported(p, q):
     return 0 < p <= 288 and 0 < q <= 128 and p % 4 == 0 and q % 4 == 0
 

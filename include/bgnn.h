@@ -150,6 +150,19 @@ int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t 
                                 const float* gconst /*[2]*/, const float* wd /*[2][2D]*/, const double* counts /*[2]*/,
                                 float* Gall, int32_t p, int64_t ld_gall, float* side_opt, int64_t ld_side,
                                 float* ex_opt /*[p][4]*/, void* ws_opt, size_t ws_bytes, void* stream);
+/* The O(D x Din) algebra around the streaming launches of the transform backward (KTGNN.py:275-284 under autograd), one launch
+ *   each.  consts: gx [2][din] = the x-halves of the gate vectors g1 = a_g_s2t, g2 = a_g_t2s ([x || delta] order, 2*din each),
+ *   gconst [2] = delta . (their delta-halves), wd [2][2D] as bgnn_transform_bwd_prep_f32 takes it.  finish: from dWall = Gall^T x
+ *   [p][din] and ex [p][4]: dW_t = dWall[:D] - u1 (x) delta, dW_s = dWall[D:2D] + u2 (x) delta, dg_g = [dWall[2D+g] | sp_g delta],
+ *   db_t / db_s = ex[:D,2] / ex[D:2D,2], and wcat_t [din][ld_wcat] = the TRANSPOSED operand (W_t | W_s | g1_x | g2_x | ddl | 0) of
+ *   the input-gradient launch dX = Gall . Wcat (ddl = sp_0 g1_d + sp_1 g2_d - W_t^T u1 + W_s^T u2: through the domain means).
+ *   W_s, W_t are [D][din] contiguous. */
+int bgnn_transform_bwd_consts_f32(const float* W_s, const float* W_t, const float* g1, const float* g2, const float* delta,
+                                  int32_t D, int32_t din, float* gx, float* gconst, float* wd, void* stream);
+int bgnn_transform_bwd_finish_f32(const float* dWall, const float* ex, const float* W_s, const float* W_t, const float* g1,
+                                  const float* g2, const float* delta, int32_t D, int32_t din, int32_t p, float* dW_s,
+                                  float* dW_t, float* dg1, float* dg2, float* db_s_opt, float* db_t_opt, float* wcat_t,
+                                  int64_t ld_wcat, void* stream);
 /* bgnn_rowdot_f32: out[i][j] = X[i,:d] . V[j,:d], j < nv <= 4, d <= 256 (gate pre-activations and gate adjoints of the
  *   training path): one stream over X for all vectors. */
 int bgnn_rowdot_f32(const float* X, int64_t ldx, int64_t N, int32_t d, const float* V, int64_t ldv, int32_t nv,
