@@ -684,6 +684,127 @@ __global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
   }
 }
 
+// The same walk with one lane per (edge slot, head): lanes lg = sub * HEADS + h of a row's group.  The HEADS lanes of an edge
+// read the neighbour's HEADS consecutive 16-byte pieces -- one cache line per edge instead of HEADS separate line requests
+// from one lane (the narrow gathers are bound by the L1's line-request rate, not by bytes), the neighbour id is a broadcast
+// load, and a lane carries one head's state (fewer registers, more waves).
+template <int HEADS, int EP, int U>
+__global__ __launch_bounds__(256) void agg_heads_lanes_kernel(AggParams p) {
+  constexpr int GL = EP * HEADS, GPW = 64 / GL, RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / GL, lg = lane % GL;
+  const int sub = lg / HEADS, h = lg % HEADS;
+  const bool lane_on = g < GPW;                       // 64 % GL lanes idle
+  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);    // positions of this XCD's segment sequence (XCD balance)
+  const int64_t rs = (int64_t)HEADS * p.ldh;         // floats between consecutive nodes of a table
+  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
+    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
+    if (tile < 0) continue;
+    const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
+    const bool rvalid = lane_on && i < p.row_end;
+    const int64_t ic = rvalid ? i : p.row_begin;
+    const bool dom_s = p.mask[ic] != 0;
+    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
+    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    float4 a4;
+    a4.x = av[h * p.D];
+    a4.y = p.D > 1 ? av[h * p.D + 1] : 0.f;
+    a4.z = p.D > 2 ? av[h * p.D + 2] : 0.f;
+    a4.w = p.D > 3 ? av[h * p.D + 3] : 0.f;
+    const float4 hi = *reinterpret_cast<const float4*>(H + ic * rs + h * p.ldh);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = -INFINITY, s = 0.f;
+    if (p.mode == 2 && rvalid && sub == 0) {
+      m = p.state_ms[2 * (i * HEADS + h)];
+      s = p.state_ms[2 * (i * HEADS + h) + 1];
+      acc = *reinterpret_cast<const float4*>(p.out + (i * HEADS + h) * p.ldo);
+    }
+    const int32_t niter = (end - beg + EP * U - 1) / (EP * U);
+    for (int32_t it = 0; it < niter; ++it) {
+      int32_t id[U];
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t e = beg + it * (EP * U) + sub + u * EP;
+        id[u] = e < end ? p.col[e] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = id[u] >= 0 ? *reinterpret_cast<const float4*>(H + (int64_t)id[u] * rs + h * p.ldh) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float lg_[U], cm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float t = a4.x * leaky(v[u].x + hi.x, p.slope);
+        t = fmaf(a4.y, leaky(v[u].y + hi.y, p.slope), t);
+        t = fmaf(a4.z, leaky(v[u].z + hi.z, p.slope), t);
+        t = fmaf(a4.w, leaky(v[u].w + hi.w, p.slope), t);
+        lg_[u] = id[u] >= 0 ? t : -INFINITY;
+        cm = fmaxf(cm, lg_[u]);
+      }
+      const float mn = fmaxf(m, cm);
+      const float sc = (m == mn) ? 1.f : __expf(m - mn);
+      s *= sc;
+      acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float pe = (lg_[u] == -INFINITY) ? 0.f : __expf(lg_[u] - mn);
+        s += pe;
+        acc.x = fmaf(pe, v[u].x, acc.x); acc.y = fmaf(pe, v[u].y, acc.y);
+        acc.z = fmaf(pe, v[u].z, acc.z); acc.w = fmaf(pe, v[u].w, acc.w);
+      }
+      m = mn;
+    }
+    // merge the EP edge slots of a (row, head): partner lanes are HEADS * off apart (every lane of the wave takes part)
+#pragma unroll
+    for (int off = 1; off < EP; off <<= 1) {
+      const int src = (sub ^ off) * HEADS + h + g * GL;
+      const int from = lane_on ? src : lane;
+      const float m2 = __shfl(m, from), s2 = __shfl(s, from);
+      float4 b;
+      b.x = __shfl(acc.x, from); b.y = __shfl(acc.y, from); b.z = __shfl(acc.z, from); b.w = __shfl(acc.w, from);
+      const float mn = fmaxf(m, m2);
+      const float c1 = (m == mn) ? 1.f : __expf(m - mn), c2 = (m2 == mn) ? 1.f : __expf(m2 - mn);
+      s = s * c1 + s2 * c2;
+      acc.x = acc.x * c1 + b.x * c2; acc.y = acc.y * c1 + b.y * c2;
+      acc.z = acc.z * c1 + b.z * c2; acc.w = acc.w * c1 + b.w * c2;
+      m = mn;
+    }
+    if (rvalid && sub == 0) {
+      float* o = p.out + (i * HEADS + h) * p.ldo;
+      if (p.mode == 1 && i >= p.park_begin) {
+        p.state_ms[2 * (i * HEADS + h)] = m;
+        p.state_ms[2 * (i * HEADS + h) + 1] = s;
+        *reinterpret_cast<float4*>(o) = acc;
+      } else {
+        const float inv = 1.f / (s + 1e-16f);
+        float4 r = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (p.mode == 3) {       // training: the softmax state of the finished row, for the heads backward
+          p.state_ms[2 * (i * HEADS + h)] = m;
+          p.state_ms[2 * (i * HEADS + h) + 1] = s;
+        }
+        if (p.ep_relu == 2) {    // log_softmax over the head's D classes (KTGNN.py:435), row-local
+          float mx = r.x;
+          if (p.D > 1) mx = fmaxf(mx, r.y);
+          if (p.D > 2) mx = fmaxf(mx, r.z);
+          if (p.D > 3) mx = fmaxf(mx, r.w);
+          float se = expf(r.x - mx);
+          if (p.D > 1) se += expf(r.y - mx);
+          if (p.D > 2) se += expf(r.z - mx);
+          if (p.D > 3) se += expf(r.w - mx);
+          const float lse = logf(se);
+          r.x = r.x - mx - lse;
+          r.y = p.D > 1 ? r.y - mx - lse : 0.f;
+          r.z = p.D > 2 ? r.z - mx - lse : 0.f;
+          r.w = p.D > 3 ? r.w - mx - lse : 0.f;
+        }
+        *reinterpret_cast<float4*>(o) = r;
+      }
+    }
+  }
+}
+
 // Tiles per queue claim.  4 amortises the same-address atomic (~90 ns each); measured on a rank's share of C4
 // (tools/rank_of_8_time.py): 1 -> 0.80 ms, 2 -> 0.69, 4 -> 0.67, 8 -> 0.70 per forward, also for the short launches.
 inline int tq_chunk_for(int64_t ntiles, int64_t grid) {
@@ -692,23 +813,38 @@ inline int tq_chunk_for(int64_t ntiles, int64_t grid) {
   return forced > 0 ? forced : 4;
 }
 
-template <int HEADS, int EP, int U>
-int launch_heads(const AggParams& p, hipStream_t st) {
-  constexpr int RPB = 4 * (64 / EP);
+template <int HEADS, int EP, int U, bool LANES>
+int launch_heads_v(const AggParams& p, hipStream_t st) {
+  constexpr int RPB = LANES ? 4 * (64 / (EP * HEADS)) : 4 * (64 / EP);
   static const int cap = [] {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_kernel<HEADS, EP, U>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+    const hipError_t e = LANES ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_lanes_kernel<HEADS, EP, U>, 256, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_kernel<HEADS, EP, U>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) return 2048;
     if (per_cu > 8) per_cu = 8;
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
   const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((agg_heads_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  if (LANES) hipLaunchKernelGGL((agg_heads_lanes_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((agg_heads_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
   BGNN_LAUNCH_CHECK();
   return 0;
+}
+
+template <int HEADS, int EP, int U>
+int launch_heads(const AggParams& p, hipStream_t st) {
+  // BGNN_HEADS_CFG (tools/heads_fwd_time.py sweep only).  C4, three heads: one lane for all heads (EP 4, U 4) 0.240 ms;
+  // lane per head: EP/U 4/4 0.222, 4/2 0.247, 8/2 0.378, 2/2 0.223, 2/4 0.188, 2/8 0.192, 1/4 0.189, 1/8 0.184 ms
+  // (2/4 kept: EP = 1 leaves a hub row's whole edge list to one lane triple)
+  static const int cfg = [] { const char* e = getenv("BGNN_HEADS_CFG"); return e ? atoi(e) : 0; }();
+  if (cfg == 1) return launch_heads_v<HEADS, EP, U, false>(p, st);
+  if (cfg == 44) return launch_heads_v<HEADS, 4, 4, true>(p, st);
+  if (cfg == 14) return launch_heads_v<HEADS, 1, 4, true>(p, st);
+  return launch_heads_v<HEADS, 2, 4, true>(p, st);
 }
 
 // Persistent grid = exactly the blocks that are co-resident (occupancy x CUs): a larger grid would
