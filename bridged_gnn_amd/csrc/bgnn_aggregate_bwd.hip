@@ -530,190 +530,174 @@ __device__ __forceinline__ EdgeTerm edge_term(const float4& hj, const float4& hi
   return r;
 }
 
+// Both passes run one lane per (edge slot, head) like agg_heads_lanes_kernel (lanes lg = sub * HEADS + h of a row's group): the
+// HEADS lanes of an edge read consecutive 16-byte pieces of one line.
 template <int HEADS, int EP, int U>
 __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p) {
-  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  constexpr int GL = EP * HEADS, GPW = 64 / GL, RPB = 4 * GPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / EP, sub = lane % EP;
+  const int g = lane / GL, lg = lane % GL;
+  const int sub = lg / HEADS, h = lg % HEADS;
+  const bool lane_on = g < GPW;
   constexpr int64_t rs = HEADS * 4;
-  float4 accS[HEADS], accT[HEADS];
-#pragma unroll
-  for (int h = 0; h < HEADS; ++h) accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
   for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
     const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
     if (tile < 0) continue;
     const int64_t i = tile * RPB + wave * GPW + g;
-    const bool rvalid = i < p.N;
+    const bool rvalid = lane_on && i < p.N;
     const int64_t ic = rvalid ? i : 0;
     const bool dom_s = p.mask[ic] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
     const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
-    float4 a4[HEADS], hi[HEADS], gr[HEADS], accd[HEADS], accz[HEADS];
-    float ti[HEADS], mh[HEADS], inv[HEADS];
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-      a4[h].x = av[h * p.D];
-      a4[h].y = p.D > 1 ? av[h * p.D + 1] : 0.f;
-      a4[h].z = p.D > 2 ? av[h * p.D + 2] : 0.f;
-      a4[h].w = p.D > 3 ? av[h * p.D + 3] : 0.f;
-      hi[h] = *reinterpret_cast<const float4*>(H + ic * rs + 4 * h);
-      float4 gi = mask_cols(*reinterpret_cast<const float4*>(p.gout + ic * rs + 4 * h), p.D);
-      if (!rvalid) gi = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 oi = mask_cols(*reinterpret_cast<const float4*>(p.out + ic * rs + 4 * h), p.D);
-      if (p.log_softmax) {         // adjoint of the row-local log_softmax (pad columns stay 0)
-        const float sg = gi.x + gi.y + gi.z + gi.w;
-        gi.x -= expf(oi.x) * sg;
-        if (p.D > 1) gi.y -= expf(oi.y) * sg;
-        if (p.D > 2) gi.z -= expf(oi.z) * sg;
-        if (p.D > 3) gi.w -= expf(oi.w) * sg;
-      }
-      gr[h] = gi;
-      ti[h] = gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w;
-      mh[h] = p.state_ms[2 * (ic * HEADS + h)];
-      inv[h] = 1.f / (p.state_ms[2 * (ic * HEADS + h) + 1] + 1e-16f);
-      accd[h] = accz[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rvalid && sub == 0) {
-        float4* nd = p.node + i * (3 * HEADS);
-        nd[h] = hi[h];
-        nd[HEADS + h] = gi;
-        nd[2 * HEADS + h] = make_float4(mh[h], inv[h], ti[h], dom_s ? 1.f : 0.f);
-      }
+    float4 a4;
+    a4.x = av[h * p.D];
+    a4.y = p.D > 1 ? av[h * p.D + 1] : 0.f;
+    a4.z = p.D > 2 ? av[h * p.D + 2] : 0.f;
+    a4.w = p.D > 3 ? av[h * p.D + 3] : 0.f;
+    const float4 hi = *reinterpret_cast<const float4*>(H + ic * rs + 4 * h);
+    float4 gi = mask_cols(*reinterpret_cast<const float4*>(p.gout + ic * rs + 4 * h), p.D);
+    if (!rvalid) gi = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 oi = mask_cols(*reinterpret_cast<const float4*>(p.out + ic * rs + 4 * h), p.D);
+    if (p.log_softmax) {           // adjoint of the row-local log_softmax (pad columns stay 0)
+      const float sg = gi.x + gi.y + gi.z + gi.w;
+      gi.x -= expf(oi.x) * sg;
+      if (p.D > 1) gi.y -= expf(oi.y) * sg;
+      if (p.D > 2) gi.z -= expf(oi.z) * sg;
+      if (p.D > 3) gi.w -= expf(oi.w) * sg;
     }
+    const float ti = gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w;
+    const float mh = p.state_ms[2 * (ic * HEADS + h)];
+    const float inv = 1.f / (p.state_ms[2 * (ic * HEADS + h) + 1] + 1e-16f);
+    if (rvalid && sub == 0) {
+      float4* nd = p.node + i * (3 * HEADS);
+      nd[h] = hi;
+      nd[HEADS + h] = gi;
+      nd[2 * HEADS + h] = make_float4(mh, inv, ti, dom_s ? 1.f : 0.f);
+    }
+    float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accz = accd;
     for (int32_t e0 = beg + sub; e0 < end; e0 += EP * U) {
       int32_t jj[U];
-      float4 hj[U][HEADS];
+      float4 hj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) jj[u] = e0 + u * EP < end ? p.col[e0 + u * EP] : -1;
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h) hj[u][h] = *reinterpret_cast<const float4*>(H + (int64_t)max(jj[u], 0) * rs + 4 * h);
+      for (int u = 0; u < U; ++u) hj[u] = *reinterpret_cast<const float4*>(H + (int64_t)max(jj[u], 0) * rs + 4 * h);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (jj[u] < 0) continue;
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-          const EdgeTerm t = edge_term(hj[u][h], hi[h], a4[h], gr[h], mh[h], inv[h], ti[h], p.slope);
-          accd[h].x += t.de * a4[h].x * t.lk.x; accd[h].y += t.de * a4[h].y * t.lk.y;
-          accd[h].z += t.de * a4[h].z * t.lk.z; accd[h].w += t.de * a4[h].w * t.lk.w;
-          accz[h].x += t.de * t.lz.x; accz[h].y += t.de * t.lz.y; accz[h].z += t.de * t.lz.z; accz[h].w += t.de * t.lz.w;
-        }
+        const EdgeTerm t = edge_term(hj[u], hi, a4, gi, mh, inv, ti, p.slope);
+        accd.x += t.de * a4.x * t.lk.x; accd.y += t.de * a4.y * t.lk.y;
+        accd.z += t.de * a4.z * t.lk.z; accd.w += t.de * a4.w * t.lk.w;
+        accz.x += t.de * t.lz.x; accz.y += t.de * t.lz.y; accz.z += t.de * t.lz.z; accz.w += t.de * t.lz.w;
       }
     }
 #pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-#pragma unroll
-      for (int off = 1; off < EP; off <<= 1) {
-        accd[h].x += __shfl_xor(accd[h].x, off); accd[h].y += __shfl_xor(accd[h].y, off);
-        accd[h].z += __shfl_xor(accd[h].z, off); accd[h].w += __shfl_xor(accd[h].w, off);
-      }
-      if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.dstside + i * rs + 4 * h) = accd[h];
-      if (rvalid) {
-        if (dom_s) { accS[h].x += accz[h].x; accS[h].y += accz[h].y; accS[h].z += accz[h].z; accS[h].w += accz[h].w; }
-        else       { accT[h].x += accz[h].x; accT[h].y += accz[h].y; accT[h].z += accz[h].z; accT[h].w += accz[h].w; }
-      }
+    for (int off = 1; off < EP; off <<= 1) {      // the EP edge slots of a (row, head): partner lanes are HEADS * off apart
+      const int from = lane_on ? (sub ^ off) * HEADS + h + g * GL : lane;
+      accd.x += __shfl(accd.x, from); accd.y += __shfl(accd.y, from);
+      accd.z += __shfl(accd.z, from); accd.w += __shfl(accd.w, from);
+    }
+    if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.dstside + i * rs + 4 * h) = accd;
+    if (rvalid) {
+      if (dom_s) { accS.x += accz.x; accS.y += accz.y; accS.z += accz.z; accS.w += accz.w; }
+      else       { accT.x += accz.x; accT.y += accz.y; accT.z += accz.z; accT.w += accz.w; }
     }
   }
-  // da: wave reduction, then one atomic per (wave, head, column, domain)
-#pragma unroll
-  for (int h = 0; h < HEADS; ++h) {
-    float v[8] = {accS[h].x, accS[h].y, accS[h].z, accS[h].w, accT[h].x, accT[h].y, accT[h].z, accT[h].w};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      v[c] = bgnn::group_sum<64>(v[c]);
-      if (lane == 0 && (c & 3) < p.D) unsafeAtomicAdd(c < 4 ? &p.da_t2s[h * p.D + c] : &p.da_s2t[h * p.D + c - 4], v[c]);
-    }
+  // da: block reduction per (head, column, domain) in LDS, one atomic each per block
+  __shared__ float red[2][HEADS][4];
+  if (threadIdx.x < 2 * HEADS * 4) (&red[0][0][0])[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (lane_on) {
+    unsafeAtomicAdd(&red[0][h][0], accS.x); unsafeAtomicAdd(&red[0][h][1], accS.y);
+    unsafeAtomicAdd(&red[0][h][2], accS.z); unsafeAtomicAdd(&red[0][h][3], accS.w);
+    unsafeAtomicAdd(&red[1][h][0], accT.x); unsafeAtomicAdd(&red[1][h][1], accT.y);
+    unsafeAtomicAdd(&red[1][h][2], accT.z); unsafeAtomicAdd(&red[1][h][3], accT.w);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * HEADS * 4) {
+    const int d = threadIdx.x / (HEADS * 4), hh = (threadIdx.x / 4) % HEADS, c = threadIdx.x & 3;
+    if (c < p.D) unsafeAtomicAdd(d == 0 ? &p.da_t2s[hh * p.D + c] : &p.da_s2t[hh * p.D + c], red[d][hh][c]);
   }
 }
 
 template <int HEADS, int EP, int U>
 __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p) {
-  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
+  constexpr int GL = EP * HEADS, GPW = 64 / GL, RPB = 4 * GPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / EP, sub = lane % EP;
+  const int g = lane / GL, lg = lane % GL;
+  const int sub = lg / HEADS, h = lg % HEADS;
+  const bool lane_on = g < GPW;
   constexpr int64_t rs = HEADS * 4;
-  float4 aS[HEADS], aT[HEADS];
-#pragma unroll
-  for (int h = 0; h < HEADS; ++h) {
-    aS[h].x = p.a_t2s[h * p.D]; aS[h].y = p.D > 1 ? p.a_t2s[h * p.D + 1] : 0.f;
-    aS[h].z = p.D > 2 ? p.a_t2s[h * p.D + 2] : 0.f; aS[h].w = p.D > 3 ? p.a_t2s[h * p.D + 3] : 0.f;
-    aT[h].x = p.a_s2t[h * p.D]; aT[h].y = p.D > 1 ? p.a_s2t[h * p.D + 1] : 0.f;
-    aT[h].z = p.D > 2 ? p.a_s2t[h * p.D + 2] : 0.f; aT[h].w = p.D > 3 ? p.a_s2t[h * p.D + 3] : 0.f;
-  }
+  float4 aS, aT;
+  aS.x = p.a_t2s[h * p.D]; aS.y = p.D > 1 ? p.a_t2s[h * p.D + 1] : 0.f;
+  aS.z = p.D > 2 ? p.a_t2s[h * p.D + 2] : 0.f; aS.w = p.D > 3 ? p.a_t2s[h * p.D + 3] : 0.f;
+  aT.x = p.a_s2t[h * p.D]; aT.y = p.D > 1 ? p.a_s2t[h * p.D + 1] : 0.f;
+  aT.z = p.D > 2 ? p.a_s2t[h * p.D + 2] : 0.f; aT.w = p.D > 3 ? p.a_s2t[h * p.D + 3] : 0.f;
   const int64_t ntiles = (p.N + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
   for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
     const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
     if (tile < 0) continue;
     const int64_t j = tile * RPB + wave * GPW + g;
-    const bool rvalid = j < p.N;
+    const bool rvalid = lane_on && j < p.N;
     const int64_t jc = rvalid ? j : 0;
     const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
-    float4 hS[HEADS], hT[HEADS], accS[HEADS], accT[HEADS];   // row j of both tables: the destination's domain picks one
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-      hS[h] = *reinterpret_cast<const float4*>(p.h_t2s + jc * rs + 4 * h);
-      hT[h] = *reinterpret_cast<const float4*>(p.h_s2t + jc * rs + 4 * h);
-      accS[h] = accT[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // row j of both tables: the destination's domain picks one
+    const float4 hS = *reinterpret_cast<const float4*>(p.h_t2s + jc * rs + 4 * h);
+    const float4 hT = *reinterpret_cast<const float4*>(p.h_s2t + jc * rs + 4 * h);
+    float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
     for (int32_t k0 = beg + sub; k0 < end; k0 += EP * U) {
       int32_t ii[U];
-      float4 nd[U][3 * HEADS];
+      float4 nh[U], ng[U], ns[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) ii[u] = k0 + u * EP < end ? p.t_dst[k0 + u * EP] : -1;
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int c = 0; c < 3 * HEADS; ++c) nd[u][c] = p.node[(int64_t)max(ii[u], 0) * (3 * HEADS) + c];
+      for (int u = 0; u < U; ++u) {
+        const float4* nd = p.node + (int64_t)max(ii[u], 0) * (3 * HEADS);
+        nh[u] = nd[h]; ng[u] = nd[HEADS + h]; ns[u] = nd[2 * HEADS + h];
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (ii[u] < 0) continue;
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-          const float4 st = nd[u][2 * HEADS + h];        // (m, 1/s, t_i, domain of i)
-          const bool ds = st.w != 0.f;
-          const float4 a4 = ds ? aS[h] : aT[h];
-          const float4 gr = nd[u][HEADS + h];
-          const EdgeTerm t = edge_term(ds ? hS[h] : hT[h], nd[u][h], a4, gr, st.x, st.y, st.z, p.slope);
-          float4 v;
-          v.x = fmaf(t.al, gr.x, t.de * a4.x * t.lk.x); v.y = fmaf(t.al, gr.y, t.de * a4.y * t.lk.y);
-          v.z = fmaf(t.al, gr.z, t.de * a4.z * t.lk.z); v.w = fmaf(t.al, gr.w, t.de * a4.w * t.lk.w);
-          if (ds) { accS[h].x += v.x; accS[h].y += v.y; accS[h].z += v.z; accS[h].w += v.w; }
-          else    { accT[h].x += v.x; accT[h].y += v.y; accT[h].z += v.z; accT[h].w += v.w; }
-        }
+        const bool ds = ns[u].w != 0.f;              // (m, 1/s, t_i, domain of i)
+        const float4 a4 = ds ? aS : aT;
+        const EdgeTerm t = edge_term(ds ? hS : hT, nh[u], a4, ng[u], ns[u].x, ns[u].y, ns[u].z, p.slope);
+        float4 v;
+        v.x = fmaf(t.al, ng[u].x, t.de * a4.x * t.lk.x); v.y = fmaf(t.al, ng[u].y, t.de * a4.y * t.lk.y);
+        v.z = fmaf(t.al, ng[u].z, t.de * a4.z * t.lk.z); v.w = fmaf(t.al, ng[u].w, t.de * a4.w * t.lk.w);
+        if (ds) { accS.x += v.x; accS.y += v.y; accS.z += v.z; accS.w += v.w; }
+        else    { accT.x += v.x; accT.y += v.y; accT.z += v.z; accT.w += v.w; }
       }
     }
     const bool dom_j = rvalid && p.mask[jc] != 0;
 #pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-#pragma unroll
-      for (int off = 1; off < EP; off <<= 1) {
-        accS[h].x += __shfl_xor(accS[h].x, off); accS[h].y += __shfl_xor(accS[h].y, off);
-        accS[h].z += __shfl_xor(accS[h].z, off); accS[h].w += __shfl_xor(accS[h].w, off);
-        accT[h].x += __shfl_xor(accT[h].x, off); accT[h].y += __shfl_xor(accT[h].y, off);
-        accT[h].z += __shfl_xor(accT[h].z, off); accT[h].w += __shfl_xor(accT[h].w, off);
-      }
-      if (rvalid && sub == 0) {
-        const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * rs + 4 * h);
-        if (dom_j) { accS[h].x += ds4.x; accS[h].y += ds4.y; accS[h].z += ds4.z; accS[h].w += ds4.w; }
-        else       { accT[h].x += ds4.x; accT[h].y += ds4.y; accT[h].z += ds4.z; accT[h].w += ds4.w; }
-        *reinterpret_cast<float4*>(p.dh_t2s + j * rs + 4 * h) = accS[h];
-        *reinterpret_cast<float4*>(p.dh_s2t + j * rs + 4 * h) = accT[h];
-      }
+    for (int off = 1; off < EP; off <<= 1) {
+      const int from = lane_on ? (sub ^ off) * HEADS + h + g * GL : lane;
+      accS.x += __shfl(accS.x, from); accS.y += __shfl(accS.y, from); accS.z += __shfl(accS.z, from); accS.w += __shfl(accS.w, from);
+      accT.x += __shfl(accT.x, from); accT.y += __shfl(accT.y, from); accT.z += __shfl(accT.z, from); accT.w += __shfl(accT.w, from);
+    }
+    if (rvalid && sub == 0) {
+      const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * rs + 4 * h);
+      if (dom_j) { accS.x += ds4.x; accS.y += ds4.y; accS.z += ds4.z; accS.w += ds4.w; }
+      else       { accT.x += ds4.x; accT.y += ds4.y; accT.z += ds4.z; accT.w += ds4.w; }
+      *reinterpret_cast<float4*>(p.dh_t2s + j * rs + 4 * h) = accS;
+      *reinterpret_cast<float4*>(p.dh_s2t + j * rs + 4 * h) = accT;
     }
   }
 }
 
 template <int HEADS>
 int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
-  // (EP, U) from a sweep on C4 (tools/heads_bwd_time.py); env override for that sweep only
+  // (EP, U) from a sweep on C4 (tools/heads_bwd_time.py; env override for that sweep only), both passes together:
+  // lane per head 2/4 0.69, 1/4 0.70, 1/2 0.73, 2/2 0.74, 4/4 0.74, 4/2 0.80 ms (one lane for all heads: 1.33 ms)
   static const int cfg = [] { const char* e = getenv("BGNN_HEADS_BWD_CFG"); return e ? atoi(e) : 0; }();
 #define BGNN_HB(EPV, UV)                                                                                               \
   do {                                                                                                                 \
-    constexpr int RPB = 4 * (64 / EPV);                                                                                \
+    constexpr int RPB = 4 * (64 / (EPV * HEADS));                                                                      \
     const int64_t ntiles = (p.N + RPB - 1) / RPB;                                                                      \
     int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;                                                        \
     if (grid < 8) grid = 8;                                                                                            \
@@ -723,11 +707,12 @@ int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
     BGNN_LAUNCH_CHECK();                                                                                               \
     return 0;                                                                                                          \
   } while (0)
-  if (cfg == 81) BGNN_HB(8, 1);
-  if (cfg == 82) BGNN_HB(8, 2);
   if (cfg == 44) BGNN_HB(4, 4);
-  if (cfg == 41) BGNN_HB(4, 1);
-  BGNN_HB(4, 2);                                 // C4: 8/1 1.45, 8/2 1.42, 4/1 1.38, 4/2 1.33, 4/4 1.33 ms for the two passes
+  if (cfg == 42) BGNN_HB(4, 2);
+  if (cfg == 22) BGNN_HB(2, 2);
+  if (cfg == 14) BGNN_HB(1, 4);
+  if (cfg == 12) BGNN_HB(1, 2);
+  BGNN_HB(2, 4);
 #undef BGNN_HB
 }
 

@@ -1,7 +1,7 @@
 """time the three-head classifier aggregation (forward + backward) on the C4 graph for the (EP, U) variants of the backward"""
 import os, sys, subprocess
 if len(sys.argv) == 1:
-    for cfg in ("81", "82", "41", "42", "44"):
+    for cfg in ("24", "44", "42", "22", "14", "12"):
         env = dict(os.environ, BGNN_HEADS_BWD_CFG=cfg)
         subprocess.run([sys.executable, __file__, cfg], env=env, check=True)
     sys.exit(0)
