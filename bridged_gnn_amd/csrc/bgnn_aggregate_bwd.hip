@@ -132,7 +132,7 @@ int launch_bwd(const BwdParams& p, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Atomic-free ("pull") form for wide rows (36 <= D <= 128).  The scatter above moves E' x 4D bytes through float
+// Atomic-free ("pull") form (D <= 128; rows of one float4 with ldh = 4 take the narrow kernels further down).  The scatter above moves E' x 4D bytes through float
 // atomics, which retire at ~1.3 TB/s on MI355X (8.96 ms for the C4 hidden conv).  Here the source-side sums are GATHERED
 // over a by-source (transposed) CSR instead:
 //   pass A (by destination, same walk as the forward): t_i, c_ji, de_ji; the destination-side sums go to a plain
@@ -784,7 +784,7 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
       !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
     return BGNN_E_NULL;
   const bool narrow = D >= 1 && D <= 4 && ldh == 4 && ldo == 4 && ldg == 4;
-  if (N < 0 || E < 0 || (!narrow && (D <= 32 || D > 128)) || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
+  if (N < 0 || E < 0 || D < 1 || D > 128 || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
       !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
     return BGNN_E_ALIGN;
@@ -799,6 +799,9 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
   if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (narrow) return launch_pull_narrow(p, st);
   const int nv = (D + 3) / 4;
+  if (nv <= 2) return launch_pull<2>(p, st);
+  if (nv <= 4) return launch_pull<4>(p, st);
+  if (nv <= 8) return launch_pull<8>(p, st);
   return nv <= 16 ? launch_pull<16>(p, st) : launch_pull<32>(p, st);
 }
 

@@ -418,9 +418,9 @@ def adaptedconv_aggregate_bwd(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, out, 
     da_t2s = torch.zeros(D, dtype=torch.float32, device=dev)
     da_s2t = torch.zeros(D, dtype=torch.float32, device=dev)
     grad_out = grad_out.contiguous()
-    narrow = D <= 4 and h_t2s.stride(0) == 4 and out.stride(0) == 4 and grad_out.stride(0) == 4
-    if (32 < D <= 128 or narrow) and grad_out.stride(0) % 4 == 0 and grad_out.data_ptr() % 16 == 0 and h_t2s.shape[0] == csr.num_nodes:
-        # wide rows: atomic-free pull over the by-source CSR (float atomics retire at ~1.3 TB/s on MI355X)
+    if D <= 128 and grad_out.stride(0) % 4 == 0 and grad_out.data_ptr() % 16 == 0 and h_t2s.shape[0] == csr.num_nodes:
+        # atomic-free pull over the by-source CSR (float atomics retire at ~1.3 TB/s on MI355X); the atomic form remains for
+        # D > 128 and for row ranges
         t_rowptr, t_eid, t_dst = csr.transposed()
         dh_t2s, dh_s2t = torch.empty_like(h_t2s), torch.empty_like(h_s2t)
         wsb = lib.bgnn_aggregate_bwd_pull_workspace_bytes(csr.num_nodes, csr.num_edges, h_t2s.stride(0))

@@ -241,7 +241,7 @@ int bgnn_adaptedconv_aggregate_bwd_f32(const float* h_t2s, const float* h_s2t, i
                                        float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
                                        void* stream);
 
-/* Atomic-free ("pull") form of the same backward for 32 < D <= 128 and for D <= 4 with ldh = ldo = ldg = 4: the source-side sums are gathered over a by-source
+/* Atomic-free ("pull") form of the same backward for D <= 128: the source-side sums are gathered over a by-source
  * view of the edges (t_rowptr [N+1]; t_eid [E'] = position of the edge in the by-destination order; t_dst [E'] = its
  * destination) instead of scattered with float atomics; every dH row is written exactly once (no zero-fill needed,
  * deterministic).  All N rows are visited; ws: bgnn_aggregate_bwd_pull_workspace_bytes(N, E', ldh). */

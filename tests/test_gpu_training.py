@@ -39,10 +39,53 @@ def test_adaptedconv_gradients_vs_autograd_oracle(din, D, n):
     e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
     oo = OT.adaptedconv(xo, mo, e1, e2, p)
     (oo * torch.from_numpy(w).double()).sum().backward()
-    assert _rel(out.detach().cpu().double(), oo.detach()) < 2e-5
-    assert _rel(xg.grad.cpu().double(), xo.grad) < 2e-4, "dL/dx"
+    # measured (tools/grad_error_table.py): every tensor <= 1.2e-6 on these shapes.  The bar leaves room for ONE leaky-relu
+    # kink flip: h_j + h_i is formed from fp32 tables, the oracle's from fp64 ones, and an element within rounding of 0 takes
+    # slope 1 on one side and 0.1 on the other -- the end-to-end error then jumps to 1e-4..1e-3 for that element although the
+    # backward itself is exact to 1e-7 (test_aggregation_backward_exact_on_the_same_tables shows exactly that case)
+    assert _rel(out.detach().cpu().double(), oo.detach()) < 2e-6
+    assert _rel(xg.grad.cpu().double(), xo.grad) < 2e-5, "dL/dx"
     for name, prm in conv.named_parameters():
-        assert _rel(prm.grad.cpu().double(), p[name].grad) < 2e-4, name
+        assert _rel(prm.grad.cpu().double(), p[name].grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("D,n", [(128, 6000), (2, 6000), (16, 3000)])
+def test_aggregation_backward_exact_on_the_same_tables(D, n):
+    """The aggregation backward against fp64 autograd ON THE SAME fp32 TABLES (so no leaky-relu kink can flip between the two
+    sides): <= 1e-6 for every table element and both attention vectors.  At (D, n) = (128, 6000) the end-to-end comparison
+    with an fp64 forward (tools/grad_error_table.py) shows 8e-4 on the t2s side -- one kink flip from the tables' fp32
+    rounding, not an error of the backward; this test pins that statement."""
+    import torch.nn.functional as F
+    from bridged_gnn_amd import ops, synth
+    from bridged_gnn_amd.ktgnn import _AggregateFn
+    ei, mask = synth.random_multigraph(n, 8 * n, frac_src=0.45, n_isolated=3, seed=n + D)
+    rng = np.random.default_rng(D)
+    ld = ops.pad4(D)
+    tabs = []
+    for _ in range(2):
+        t = np.zeros((n, ld), np.float32)
+        t[:, :D] = rng.standard_normal((n, D)).astype(np.float32)
+        tabs.append(t)
+    a = rng.standard_normal((2, D)).astype(np.float32) * 0.3
+    w = rng.standard_normal((n, D)).astype(np.float32)
+    csr = ops.build_dst_csr(_t(ei), n)
+    m8 = _t(mask).to(torch.uint8)
+    g1, g2 = _t(tabs[0]).requires_grad_(True), _t(tabs[1]).requires_grad_(True)
+    ga1, ga2 = _t(a[0]).requires_grad_(True), _t(a[1]).requires_grad_(True)
+    out = _AggregateFn.apply(g1, g2, ga1, ga2, csr, m8, D, 0.1)[:, :D]
+    (out * _t(w)).sum().backward()
+    mo = torch.from_numpy(mask)
+    e1, e2 = OT.graph_partition(torch.from_numpy(ei), mo)
+    t1 = torch.from_numpy(tabs[0][:, :D]).double().requires_grad_(True); t2 = torch.from_numpy(tabs[1][:, :D]).double().requires_grad_(True)
+    b1 = torch.from_numpy(a[0]).double().requires_grad_(True); b2 = torch.from_numpy(a[1]).double().requires_grad_(True)
+    al = OT.segment_softmax(torch.cat((F.leaky_relu(t1[e1[0]] + t1[e1[1]], 0.1) @ b1, F.leaky_relu(t2[e2[0]] + t2[e2[1]], 0.1) @ b2)),
+                            torch.cat((e1[1], e2[1])), n)
+    o = torch.zeros(n, D, dtype=torch.float64)
+    o = o.index_add(0, e1[1], t1[e1[0]] * al[: e1.shape[1], None]).index_add(0, e2[1], t2[e2[0]] * al[e1.shape[1]:, None])
+    (o * torch.from_numpy(w).double()).sum().backward()
+    assert _rel(out.detach().cpu().double(), o.detach()) < 1e-6
+    assert _rel(g1.grad[:, :D].cpu().double(), t1.grad) < 1e-6 and _rel(g2.grad[:, :D].cpu().double(), t2.grad) < 1e-6
+    assert _rel(ga1.grad.cpu().double(), b1.grad) < 3e-6 and _rel(ga2.grad.cpu().double(), b2.grad) < 3e-6
 
 
 @pytest.mark.parametrize("p,q,n", [(260, 128, 5000), (8, 128, 3333), (36, 4, 1025), (288, 64, 700), (4, 4, 5)])
@@ -69,13 +112,13 @@ def test_rowdot_kernel_vs_fp64(d, nv, n):
     assert _rel(got, ref) < 1e-5
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(20))
 def test_pull_backward_equals_atomic_backward(seed):
     """the atomic-free pull form and the atomic scatter form of the aggregation backward are the same function: compare
-    them against each other on seeded random shapes inside the pull envelope (D <= 4 and 32 < D <= 128)."""
+    them against each other on seeded random shapes over the pull envelope (D <= 128: every lane-group width)."""
     from bridged_gnn_amd import _lib, ops, synth
     rng = np.random.default_rng(300 + seed)
-    D = int(rng.choice([1, 2, 3, 4, 36, 40, 64, 100, 128]))
+    D = int([1, 2, 3, 4, 36, 40, 64, 100, 128, 5, 8, 12, 16, 17, 24, 31, 32, 33, 7, 96][seed])
     n = int(rng.integers(40, 2500))
     ei, mask = synth.random_multigraph(n, int(rng.integers(1, 10)) * n, frac_src=float(rng.uniform(0.2, 0.8)), n_isolated=2, seed=seed)
     csr = ops.build_dst_csr(_t(ei), n)
