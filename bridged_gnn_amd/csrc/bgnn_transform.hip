@@ -390,7 +390,11 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
   // MODE 2 second stage: out2[o][row] = sum_c w2[o][c] * a[row][c] over this wave's 32 columns as 16 fp32 MFMAs whose B
   // operands are the activation registers as they are (register 4q+j of lane (fr, fh) = column 8q+4fh+j of row fr, i.e.
   // k-pair {8q+j, 8q+4+j}); the stationary A operand pairs the same way: w2r[4q+j] = w2[o = fr][col_base + 8q+4fh+j]
-  float w2r[MODE == 2 ? 16 : 1];
+  // (BF3: the second stage runs on the bf16 matrix cores too -- the 16 activation registers of a lane ARE two k-blocks of a
+  //  32x32x16 B operand once split into bf16 pieces (k-slot = register index, the same permutation on the stationary side);
+  //  six products per k-block: 12 x 32 cycles instead of 16 fp32 MFMAs x 64 cycles on the vector ALU)
+  float w2r[MODE == 2 && !BF3 ? 16 : 1];
+  bf16x8 w2p[MODE == 2 && BF3 ? 3 : 1][2];   // [piece][k-block]
   if constexpr (MODE == 2) {                 // host: gridDim.y == 1, NC == 32 * NCT
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -400,7 +404,15 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
         float v = 0.f;
         if (fr < 8) v = p.w2[(int64_t)fr * p.NC + c];
         else if (fr < 10) v = p.g2[(int64_t)(fr - 8) * 2 * p.NC + c];
-        w2r[4 * q + j] = v;
+        if constexpr (BF3) {
+          const __bf16 h = (__bf16)v;
+          const float r1 = v - (float)h;
+          const __bf16 m = (__bf16)r1;
+          const int r = 4 * q + j;
+          w2p[0][r >> 3][r & 7] = h; w2p[1][r >> 3][r & 7] = m; w2p[2][r >> 3][r & 7] = (__bf16)(r1 - (float)m);
+        } else {
+          w2r[4 * q + j] = v;
+        }
       }
     for (int t = tid; t < NCT * BMW * R2_LD; t += 64 * NW) (&red2[0][0])[t] = 0.f;   // (columns 10, 11 stay zero)
     // (the first __syncthreads of the tile loop orders these writes before their first use)
@@ -660,8 +672,29 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
       f32x16 acc2;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+      if constexpr (BF3) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[r], a2[r], acc2, 0, 0, 0);
+        for (int kb = 0; kb < 2; ++kb) {
+          bf16x8 ah, am, al;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = a2[8 * kb + e];
+            const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
+            ah[e] = h; am[e] = m; al[e] = (__bf16)(r1 - (float)m);
+          }
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[2][kb], ah, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[0][kb], al, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[1][kb], am, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[1][kb], ah, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[0][kb], am, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[0][kb], ah, acc2, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[r], a2[r], acc2, 0, 0, 0);
+      }
       // accumulator register i of lane (fr, fh) is output 8*(i/4) + 4*fh + i%4 of row fr: lane half 0 holds outputs
       // 0..3 and 8..11 (8, 9 are the gate products), lane half 1 outputs 4..7
       // every column wave leaves its partial sums in its own slot (plain stores: ds_add_f32 from the NCT waves into one
