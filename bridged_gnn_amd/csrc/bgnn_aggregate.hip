@@ -887,6 +887,8 @@ int launch_wide(const AggParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_kernel<LF, U>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
     if (per_cu > 8) per_cu = 8;
+    const char* e = getenv("BGNN_AGG_BLOCKS_PER_CU");        // sweep knob (tools): fewer resident blocks = a smaller window of rows per XCD
+    if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
   const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
