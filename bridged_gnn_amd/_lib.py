@@ -56,6 +56,8 @@ SIGNATURES = {
     "bgnn_mlp_pair_topk_f32": (_INT, [_P, _P, _P, _P, _P, _F32, _I64, _I64, _I32, _I32, _INT, _P, _P, _P,
                                        _P, _SZ, _P]),
     "bgnn_topk_edges_i64": (_INT, [_P, _I64, _I32, _I64, _I64, _P, _P]),
+    "bgnn_topk_edges_coalesced_workspace_bytes": (_SZ, [_I64, _I32]),
+    "bgnn_topk_edges_coalesced_i64": (_INT, [_P, _I64, _I32, _I64, _I64, _I64, _P, _P, _SZ, _P]),
     "bgnn_gather_rows_f32": (_INT, [_P, _I64, _I64, _P, _I64, _I32, _P, _I64, _P]),
     "bgnn_coalesce_workspace_bytes": (_SZ, [_I64]),
     "bgnn_coalesce_i64": (_INT, [_P, _I64, _I64, _P, _P, _SZ, _P]),

@@ -226,7 +226,11 @@ def sharded_cosine_topk_edges(q_local, cand_local, k, rank=0, world=1, group=Non
     idx, val, nfb = be.cosine_topk(qn, cn.contiguous(), k, apply_sigmoid=apply_sigmoid)
     if events is not None:
         events[1].record()
-    ei = be.coalesce(be.topk_edges(idx, cand_base=0, query_base=int(query_base)))
+    fused = getattr(be, "topk_edges_coalesced", None)       # distinct valid candidates per query: coalescing = one stable pair sort
+    if fused is not None and k <= cn.shape[0]:
+        ei = fused(idx, cn.shape[0], cand_base=0, query_base=int(query_base))
+    else:
+        ei = be.coalesce(be.topk_edges(idx, cand_base=0, query_base=int(query_base)))
     return ei, idx, val, nfb
 
 
@@ -252,11 +256,13 @@ def add_topk_sim_cross_domain_edges(data_src, data_tar, model, epsilon=0.5, k=3,
     if world > 1:
         from .dist import all_gather_rows
         idx, probs = all_gather_rows(idx, group, world), all_gather_rows(probs, group, world)
-    edge_index_added = ops.topk_edges(idx)                                     # :61-68
+    # :61-68 + coalesce :75 -- the k candidates of a query are distinct, so the coalesced list is one stable pair sort
+    n_src = z_src.shape[0]
+    edge_index_added = ops.topk_edges_coalesced(idx, n_src) if k <= n_src else ops.coalesce(ops.topk_edges(idx))
     if verbose and hasattr(data_src, "y") and hasattr(data_tar, "y"):
         ys, yt = data_src.y.to(model.device), data_tar.y.to(model.device)
-        print("Current homophily ratio:", _homophily(ys, yt, edge_index_added))  # :71-74
-    return (ops.coalesce(edge_index_added), probs, idx,                        # :75
+        print("Current homophily ratio:", _homophily(ys, yt, edge_index_added))  # :71-74 (a ratio over the edge SET)
+    return (edge_index_added, probs, idx,                                      # :75
             model.class_probs(z_src), model.class_probs(z_tar))
 
 
@@ -268,7 +274,7 @@ def add_topk_sim_within_domain_edges(data_src, model, k=3, batch_size=1000, doma
         z = model.encode_source(data_src) if domain == "source" else model.encode_target(data_src)
     z = z.to(model.device).float().contiguous()
     idx, probs, _ = model.topk(z, z, k)
-    ei = ops.coalesce(ops.topk_edges(idx))                                     # :112-113
+    ei = ops.topk_edges_coalesced(idx, z.shape[0]) if k <= z.shape[0] else ops.coalesce(ops.topk_edges(idx))   # :112-113
     if verbose and hasattr(data_src, "y"):
         y = data_src.y.to(model.device)
         print("Current homophily ratio of Graph:", _homophily(y, y, ei))       # :116-119

@@ -228,6 +228,66 @@ extern "C" int bgnn_topk_edges_i64(const int64_t* idx, int64_t Nq, int32_t k, in
   return 0;
 }
 
+// top-k table -> COALESCED edge list in one go.  The k candidates of a query are distinct, so the list has no duplicates and
+// `coalesce` (sort by from * n + to) is a STABLE sort of the candidate ids alone when the pairs are visited query-major: 32-bit
+// key/value pairs over ceil(log2 Nc) bits (3 radix passes for 1e5 candidates) instead of 64-bit keys over 2 log2 n bits (5
+// passes), no flag / scan / compaction, and the edge count is known on the host (no device-to-host read).
+namespace {
+__global__ void topk_pairs_kernel(const int64_t* __restrict__ idx, int64_t total, int32_t k, int32_t* __restrict__ keys,
+                                  int32_t* __restrict__ vals) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    keys[t] = (int32_t)idx[t];
+    vals[t] = (int32_t)(t / k);
+  }
+}
+__global__ void topk_pairs_write_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t total,
+                                        int64_t cand_base, int64_t query_base, int64_t* __restrict__ out) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    out[t] = (int64_t)keys[t] + cand_base;
+    out[total + t] = (int64_t)vals[t] + query_base;
+  }
+}
+static size_t topk_sort_tmp_bytes(int64_t total) {
+  size_t a = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                  (size_t)total, 0, 32, (hipStream_t)0);
+  return a;
+}
+}  // namespace
+
+extern "C" size_t bgnn_topk_edges_coalesced_workspace_bytes(int64_t Nq, int32_t k) {
+  const int64_t total = Nq > 0 && k > 0 ? Nq * k : 0;
+  if (total == 0) return 256;
+  return 4 * bgnn_align_up(sizeof(int32_t) * (size_t)total, 256) + bgnn_align_up(topk_sort_tmp_bytes(total), 256) + 256;
+}
+
+extern "C" int bgnn_topk_edges_coalesced_i64(const int64_t* idx, int64_t Nq, int32_t k, int64_t Nc, int64_t cand_base,
+                                             int64_t query_base, int64_t* edge_index_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!idx || !edge_index_out || !ws) return BGNN_E_NULL;
+  if (Nq < 0 || k <= 0 || Nc < k || Nc >= (int64_t)1 << 31 || Nq >= (int64_t)1 << 31 || Nq * k >= (int64_t)1 << 31) return BGNN_E_SHAPE;
+  if (ws_bytes < bgnn_topk_edges_coalesced_workspace_bytes(Nq, k)) return BGNN_E_WORKSPACE;
+  if (Nq == 0) return 0;
+  const int64_t total = Nq * k;
+  hipStream_t st = (hipStream_t)stream;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { char* q = p; p += bgnn_align_up(bytes, 256); return q; };
+  int32_t* k0 = (int32_t*)take(sizeof(int32_t) * total);
+  int32_t* k1 = (int32_t*)take(sizeof(int32_t) * total);
+  int32_t* v0 = (int32_t*)take(sizeof(int32_t) * total);
+  int32_t* v1 = (int32_t*)take(sizeof(int32_t) * total);
+  size_t tb = topk_sort_tmp_bytes(total);
+  void* tmp = take(tb);
+  hipLaunchKernelGGL(topk_pairs_kernel, dim3(grid_for(total)), dim3(256), 0, st, idx, total, k, k0, v0);
+  int bits = 1;
+  while (bits < 31 && ((int64_t)1 << bits) < Nc) ++bits;
+  hipError_t e;
+  if ((e = rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, v1, (size_t)total, 0, bits, st)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(topk_pairs_write_kernel, dim3(grid_for(total)), dim3(256), 0, st, k1, v1, total, cand_base, query_base,
+                     edge_index_out);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ row packing (halo send lists)
 namespace {
 // one thread per 16-byte chunk: a wave reads whole rows (or several narrow rows) and writes one contiguous span

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "linear_narrow_supported", "linear_narrow_transform", "narrow_transform_finish", "gram", "gram_supported", "rowdot", "transform_bwd_prep",
+__all__ = ["DstCSR", "build_dst_csr", "domain_delta", "pack_transform_heads", "adaptedconv_transform", "adaptedconv_aggregate", "linear", "linear_supported", "linear_narrow_supported", "linear_narrow_transform", "narrow_transform_finish", "gram", "gram_supported", "rowdot", "transform_bwd_prep", "topk_edges_coalesced",
            "l2_normalize_rows", "cosine_topk", "mlp_pair_topk", "topk_edges", "coalesce", "gather_rows", "pad4"]
 
 
@@ -526,6 +526,20 @@ def topk_edges(idx, cand_base=0, query_base=0):
     out = torch.empty(2, Nq * k, dtype=torch.int64, device=idx.device)
     rc = L.lib().bgnn_topk_edges_i64(L.ptr(idx), Nq, k, int(cand_base), int(query_base), L.ptr(out), L.stream())
     L.check(rc, "bgnn_topk_edges_i64")
+    return out
+
+
+def topk_edges_coalesced(idx, n_cand, cand_base=0, query_base=0):
+    """coalesce(topk_edges(idx)) in one call for a table of DISTINCT valid candidates per query (0 <= idx < n_cand,
+    k <= n_cand: what the top-k kernels return): a stable 32-bit pair sort by candidate id, no device-to-host read."""
+    Nq, k = idx.shape
+    lib = L.lib()
+    out = torch.empty(2, Nq * k, dtype=torch.int64, device=idx.device)
+    wsb = lib.bgnn_topk_edges_coalesced_workspace_bytes(Nq, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=idx.device)
+    rc = lib.bgnn_topk_edges_coalesced_i64(L.ptr(idx), Nq, k, int(n_cand), int(cand_base), int(query_base), L.ptr(out), L.ptr(ws), wsb,
+                                           L.stream())
+    L.check(rc, "bgnn_topk_edges_coalesced_i64")
     return out
 
 

@@ -305,6 +305,14 @@ int bgnn_mlp_pair_topk_f32(const float* A_cand /*[Nc,H]*/, const float* B_query 
  * main_bridged_graph.py:61-63,:105-107.  edge_index_out is [2, Nq*k].                          */
 int bgnn_topk_edges_i64(const int64_t* idx, int64_t Nq, int32_t k, int64_t cand_base, int64_t query_base,
                         int64_t* edge_index_out, void* stream);
+/* The same table as a COALESCED edge list (what main_bridged_graph.py:75 / :113 pass on: coalesce(edge_index_added)) in one
+ * call: the k candidates of a query are distinct (0 <= idx < Nc, k <= Nc), so the list has no duplicates and coalescing is a
+ * stable sort by candidate id of the query-major pairs -- 32-bit pairs over ceil(log2 Nc) bits, exactly Nq * k edges out, no
+ * device-to-host read.  Equal to bgnn_coalesce_i64 applied to bgnn_topk_edges_i64's output.  ws:
+ * bgnn_topk_edges_coalesced_workspace_bytes(Nq, k). */
+size_t bgnn_topk_edges_coalesced_workspace_bytes(int64_t Nq, int32_t k);
+int bgnn_topk_edges_coalesced_i64(const int64_t* idx, int64_t Nq, int32_t k, int64_t Nc, int64_t cand_base, int64_t query_base,
+                                  int64_t* edge_index_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Packs table rows for a halo send list (bridged_gnn_amd/dist.py; the reference is single-device):
  * dst[r, :row_floats] = src[idx[r], :row_floats].  row_floats % 4 == 0, 16-B aligned tables with ld % 4 == 0; indices

@@ -126,11 +126,11 @@ def test_training_entry_points_reject_shapes_outside_their_envelope():
     # rowdot: more than four vectors, d > 256
     assert L.bgnn_rowdot_f32(p(x), 128, 64, 128, p(w), 128, 5, p(o), None) == -2
     assert L.bgnn_rowdot_f32(p(x), 128, 64, 260, p(w), 260, 1, p(o), None) == -2
-    # pull backward: 4 < D <= 32 has no pull form
+    # pull backward: D > 128 has no pull form (the record holds 4 x 32 sign bits per edge)
     i32 = torch.zeros(8, dtype=torch.int32, device=DEV)
     m = torch.zeros(8, dtype=torch.uint8, device=DEV)
-    rc = L.bgnn_adaptedconv_aggregate_bwd_pull_f32(p(x), p(x), 16, p(b), p(b), p(i32), p(i32), p(m), p(i32), p(i32), p(i32), 4, 0, 16, 0.1,
-                                                   p(x), 16, p(b), p(x), 16, p(o), p(o), p(b), p(b), p(ws), ws.numel(), None)
+    rc = L.bgnn_adaptedconv_aggregate_bwd_pull_f32(p(x), p(x), 132, p(b), p(b), p(i32), p(i32), p(m), p(i32), p(i32), p(i32), 4, 0, 132, 0.1,
+                                                   p(x), 132, p(b), p(x), 132, p(o), p(o), p(b), p(b), p(ws), ws.numel(), None)
     assert rc == -2
 
 
@@ -145,3 +145,18 @@ def test_gather_rows_matches_index_select(w, ld):
     assert ops.gather_rows(table, idx[:0]).shape == (0, w)
     with pytest.raises(RuntimeError):
         ops.gather_rows(table.t().contiguous().t(), idx)                   # column-major view: no unit column stride
+
+
+@pytest.mark.parametrize("nq,nc,k,seed", [(1000, 700, 20, 0), (257, 5000, 3, 1), (4, 4, 4, 2), (100000, 100000, 20, 3), (1, 9, 1, 4)])
+def test_topk_edges_coalesced_equals_coalesce_of_topk_edges(nq, nc, k, seed):
+    """bgnn_topk_edges_coalesced_i64 (one stable pair sort) == bgnn_coalesce_i64(bgnn_topk_edges_i64(...)) bit for bit, with
+    bases (main_bridged_graph.py:61-68,:75)."""
+    from bridged_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    # k distinct candidates per query, in arbitrary (top-k) order
+    idx = torch.rand(nq, nc, device=DEV, generator=g).topk(k, dim=1).indices.contiguous() if nq * nc <= 50_000_000 else \
+        (torch.randint(0, nc - k, (nq, 1), device=DEV, generator=g) + torch.randperm(k, device=DEV, generator=g)[None, :]).contiguous()
+    for cb, qb in ((0, 0), (7, 123)):
+        want = ops.coalesce(ops.topk_edges(idx, cand_base=cb, query_base=qb), num_nodes=max(nq + qb, nc + cb))
+        got = ops.topk_edges_coalesced(idx, nc, cand_base=cb, query_base=qb)
+        assert got.shape == want.shape and torch.equal(got, want)
