@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r02prof}
 mkdir -p $O
 rocprofv3 -L > $O/counters_available.txt 2>&1 || true
-B="python3 bench.py --steps 3 --warmup 1 --no-knn --no-cpu --no-graph-replay"
+B="python3 bench.py --steps 3 --warmup 1 --no-knn --no-cpu --no-graph-replay --train-steps 0"
 K="python3 bench.py --config c5 --no-cpu"
 run() { name=$1; shift; timeout -k 10 240 rocprofv3 "$@" > $O/$name.out 2> $O/$name.err || echo "$name failed rc=$?"; }
 # 1. kernel time statistics of the bench command itself
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err || echo "stats failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu --train-steps 0 > $O/bench_under_rocprof.json 2> $O/stats.err || echo "stats failed"
 # 2. HBM-side traffic (one counter per pass: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2)
 for g in local uniform; do
   run fetch_$g --pmc FETCH_SIZE -d $O/fetch_$g -o p --output-format csv -- $B --graph $g --no-uniform
