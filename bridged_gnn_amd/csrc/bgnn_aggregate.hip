@@ -53,6 +53,19 @@ struct AggParams {
   int tq_chunk;      // tiles per queue claim
   int tq_interleave; // see agg_wide_kernel
   int xcd_segments;  // see agg_wide_kernel
+  // Hub rows (agg_wide_kernel / agg_heads_lanes_kernel only).  A row is walked by ONE lane group, so a row of ~750 in-edges
+  // (the 581 source nodes of the Twitter_Graph stand-in) is a chain of ~190 dependent gather steps that outlives every other row:
+  // hub_threshold > 0 makes the launch skip rows with that many edges; they are cut into segments ("virtual rows": vrow_node[v] =
+  // the real node, `rowptr` = the segment bounds inside `col`) that a second launch parks like two-part rows (mode 1), and a merge
+  // kernel finishes them (bgnn_adaptedconv_aggregate_hub_f32).
+  // The segments ride in the SAME launch: rows [row_end, row_end + n_vrows) of the launch are virtual (vrow_node[v] = the real
+  // node, vrow_bounds[2v], [2v+1] = the segment's edges inside `col`); a virtual row always parks (m, s) in vms[v] and its raw
+  // accumulator in vout[v], whatever `mode` says for the real rows.
+  const int32_t* vrow_node;
+  const int32_t* vrow_bounds;
+  int64_t n_vrows;
+  float* vout; float* vms;
+  int32_t hub_threshold;
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -300,7 +313,8 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   const int k = lane & (U - 1);          // the edge slot of a step this lane scores
   const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 
-  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
+  const int64_t nrows_all = (p.row_end - p.row_begin) * p.heads + p.n_vrows;      // real (row, head) pairs, then hub segments
+  const int64_t ntiles = (nrows_all + RPB - 1) / RPB;
   bgnn::XcdRange tr = bgnn::xcd_tile_range(ntiles);
   __shared__ float red[2][LF * 4 + 1];
   if (p.colsum != nullptr) {
@@ -375,16 +389,27 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
       gt = (sg * 8 + xcd) * seg_len + (j - sg * seg_len);
       if (gt >= ntiles) continue;                // padding of the last segments (block-uniform)
     }
-    const int64_t i = p.row_begin * p.heads + gt * RPB + wave * GPW + g;
-    const bool rvalid = i < p.row_end * p.heads;
-    const int64_t ic = rvalid ? i : p.row_begin * p.heads;
-    const int64_t node = ic / p.heads;
-    const int head = (int)(ic - node * p.heads);
+    const int64_t i0 = p.row_begin * p.heads + gt * RPB + wave * GPW + g;
+    const int64_t vfirst = p.row_end * p.heads;                                         // first virtual row of the launch
+    const bool in_range = i0 < vfirst + p.n_vrows;
+    const bool virt = in_range && i0 >= vfirst;                                         // a hub segment (heads == 1)
+    const int64_t ic = in_range ? i0 : p.row_begin * p.heads;
+    const int64_t vix = virt ? i0 - vfirst : 0;
+    const int64_t node = virt ? (int64_t)p.vrow_node[vix] : ic / p.heads;
+    const int head = virt ? 0 : (int)(ic - node * p.heads);
+    const int64_t hrow = virt ? node : ic;                                              // the row's own table row
     const bool dom_s = p.mask[node] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = (dom_s ? p.a_t2s : p.a_s2t) + head * p.D;
-    const int32_t beg = rvalid ? p.rowptr[node] : 0;
-    const int32_t end = rvalid ? p.rowptr[node + 1] : 0;
+    // (virtual rows carry their own (begin, end) pair: hub rows are not adjacent in `col`)
+    int32_t beg = in_range ? (virt ? p.vrow_bounds[2 * vix] : p.rowptr[node]) : 0;
+    int32_t end = in_range ? (virt ? p.vrow_bounds[2 * vix + 1] : p.rowptr[node + 1]) : 0;
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;      // left to its segments
+    const bool rvalid = in_range && !hub;
+    const int64_t i = virt ? vix : i0;                                                  // index into the output / state arrays
+    float* __restrict__ obase = virt ? p.vout : p.out;
+    float* __restrict__ msbase = virt ? p.vms : p.state_ms;
+    if (hub) { beg = 0; end = 0; }
     const char* __restrict__ Hb = reinterpret_cast<const char*>(H + (int64_t)head * p.ldh + f0c);
 
     f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
@@ -396,12 +421,12 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
       a23.x = f0 + 2 < p.D ? av[f0 + 2] : 0.f;
       a23.y = f0 + 3 < p.D ? av[f0 + 3] : 0.f;
     }
-    const float4 hi4 = *reinterpret_cast<const float4*>(H + ic * p.ldh + f0c);
+    const float4 hi4 = *reinterpret_cast<const float4*>(H + hrow * p.ldh + f0c);
     const f2 h01 = {hi4.x, hi4.y}, h23 = {hi4.z, hi4.w};
 
     float m = -INFINITY, s = 0.f;          // s: per-lane partial (sum over the steps of "my" edge slot)
     f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-    if (p.mode == 2 && rvalid) {
+    if (p.mode == 2 && rvalid && !virt) {
       m = p.state_ms[2 * i];
       if (k == 0) s = p.state_ms[2 * i + 1];
       if (f0 < p.ldo) {
@@ -508,11 +533,11 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
     s += bgnn::dpp_mov<0x4E>(s);
     if constexpr (U == 8) s += bgnn::dpp_mov<0x124>(s);
 
-    if (p.mode == 1 && node >= p.park_begin) {
+    if (virt || (p.mode == 1 && node >= p.park_begin)) {
       if (rvalid) {
-        if (lg == 0) { p.state_ms[2 * i] = m; p.state_ms[2 * i + 1] = s; }
+        if (lg == 0) { msbase[2 * i] = m; msbase[2 * i + 1] = s; }
         if (f0 < p.ldo)
-          *reinterpret_cast<float4*>(p.out + i * p.ldo + f0) =
+          *reinterpret_cast<float4*>(obase + i * p.ldo + f0) =
               fvalid ? make_float4(acc01.x, acc01.y, acc23.x, acc23.y) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       continue;
@@ -695,28 +720,38 @@ __global__ __launch_bounds__(256) void agg_heads_lanes_kernel(AggParams p) {
   const int g = lane / GL, lg = lane % GL;
   const int sub = lg / HEADS, h = lg % HEADS;
   const bool lane_on = g < GPW;                       // 64 % GL lanes idle
-  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  const int64_t ntiles = (p.row_end - p.row_begin + p.n_vrows + RPB - 1) / RPB;      // real rows, then hub segments
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);    // positions of this XCD's segment sequence (XCD balance)
   const int64_t rs = (int64_t)HEADS * p.ldh;         // floats between consecutive nodes of a table
   for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
     const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
     if (tile < 0) continue;
     const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
-    const bool rvalid = lane_on && i < p.row_end;
-    const int64_t ic = rvalid ? i : p.row_begin;
-    const bool dom_s = p.mask[ic] != 0;
+    const bool in_range = lane_on && i < p.row_end + p.n_vrows;
+    const bool virt = in_range && i >= p.row_end;                          // a hub segment (AggParams)
+    const int64_t vix = virt ? i - p.row_end : 0;
+    const int64_t ic = in_range ? i : p.row_begin;
+    const int64_t node = virt ? (int64_t)p.vrow_node[vix] : ic;
+    const bool dom_s = p.mask[node] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
-    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    int32_t beg = in_range ? (virt ? p.vrow_bounds[2 * vix] : p.rowptr[ic]) : 0;
+    int32_t end = in_range ? (virt ? p.vrow_bounds[2 * vix + 1] : p.rowptr[ic + 1]) : 0;
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;
+    const bool rvalid = in_range && !hub;
+    const int64_t oi = virt ? vix : i;                                     // index into the output / state arrays
+    float* __restrict__ obase = virt ? p.vout : p.out;
+    float* __restrict__ msbase = virt ? p.vms : p.state_ms;
+    if (hub) { beg = 0; end = 0; }
     float4 a4;
     a4.x = av[h * p.D];
     a4.y = p.D > 1 ? av[h * p.D + 1] : 0.f;
     a4.z = p.D > 2 ? av[h * p.D + 2] : 0.f;
     a4.w = p.D > 3 ? av[h * p.D + 3] : 0.f;
-    const float4 hi = *reinterpret_cast<const float4*>(H + ic * rs + h * p.ldh);
+    const float4 hi = *reinterpret_cast<const float4*>(H + node * rs + h * p.ldh);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float m = -INFINITY, s = 0.f;
-    if (p.mode == 2 && rvalid && sub == 0) {
+    if (p.mode == 2 && rvalid && !virt && sub == 0) {
       m = p.state_ms[2 * (i * HEADS + h)];
       s = p.state_ms[2 * (i * HEADS + h) + 1];
       acc = *reinterpret_cast<const float4*>(p.out + (i * HEADS + h) * p.ldo);
@@ -772,10 +807,10 @@ __global__ __launch_bounds__(256) void agg_heads_lanes_kernel(AggParams p) {
       m = mn;
     }
     if (rvalid && sub == 0) {
-      float* o = p.out + (i * HEADS + h) * p.ldo;
-      if (p.mode == 1 && i >= p.park_begin) {
-        p.state_ms[2 * (i * HEADS + h)] = m;
-        p.state_ms[2 * (i * HEADS + h) + 1] = s;
+      float* o = obase + (oi * HEADS + h) * p.ldo;
+      if (virt || (p.mode == 1 && i >= p.park_begin)) {
+        msbase[2 * (oi * HEADS + h)] = m;
+        msbase[2 * (oi * HEADS + h) + 1] = s;
         *reinterpret_cast<float4*>(o) = acc;
       } else {
         const float inv = 1.f / (s + 1e-16f);
@@ -826,7 +861,7 @@ int launch_heads_v(const AggParams& p, hipStream_t st) {
     if (per_cu > 8) per_cu = 8;
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
-  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  const int64_t ntiles = (p.row_end - p.row_begin + (LANES ? p.n_vrows : 0) + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
   if (LANES) hipLaunchKernelGGL((agg_heads_lanes_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -841,7 +876,7 @@ int launch_heads(const AggParams& p, hipStream_t st) {
   // lane per head: EP/U 4/4 0.222, 4/2 0.247, 8/2 0.378, 2/2 0.223, 2/4 0.188, 2/8 0.192, 1/4 0.189, 1/8 0.184 ms
   // (2/4 kept: EP = 1 leaves a hub row's whole edge list to one lane triple)
   static const int cfg = [] { const char* e = getenv("BGNN_HEADS_CFG"); return e ? atoi(e) : 0; }();
-  if (cfg == 1) return launch_heads_v<HEADS, EP, U, false>(p, st);
+  if (cfg == 1 && p.n_vrows == 0 && p.hub_threshold == 0) return launch_heads_v<HEADS, EP, U, false>(p, st);
   if (cfg == 44) return launch_heads_v<HEADS, 4, 4, true>(p, st);
   if (cfg == 14) return launch_heads_v<HEADS, 1, 4, true>(p, st);
   return launch_heads_v<HEADS, 2, 4, true>(p, st);
@@ -891,7 +926,7 @@ int launch_wide(const AggParams& p, hipStream_t st) {
     if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
-  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + RPB - 1) / RPB;
+  const int64_t ntiles = ((p.row_end - p.row_begin) * p.heads + p.n_vrows + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
   AggParams q = p;
@@ -903,6 +938,166 @@ int launch_wide(const AggParams& p, hipStream_t st) {
   hipLaunchKernelGGL((agg_wide_kernel<LF, U>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- hub rows: merge of the parked segment states (see AggParams::hub_threshold) -------------------------------------------
+struct HubMergeParams {
+  const int32_t* hub_rows; const int32_t* seg_ptr; int64_t n_hubs;
+  const float* part_acc;   // [segments][heads * ldo]  raw accumulators (mode 1 parks them in `out`)
+  const float* part_ms;    // [segments * heads][2]    (max, sum)
+  const uint8_t* mask;
+  int32_t D; int64_t ldo; int32_t heads;
+  float* out; const float* ep_scale; const float* ep_shift; int ep_relu;
+  double* colsum; float* state_ms;
+};
+
+// wide rows (heads == 1): LF lanes own a hub row, one float4 of columns each
+template <int LF>
+__global__ __launch_bounds__(256) void hub_merge_wide_kernel(HubMergeParams p) {
+  const int lane = threadIdx.x % LF, grp = threadIdx.x / LF;
+  constexpr int GPB = 256 / LF;
+  const int f0 = lane * 4;
+  const bool fvalid = f0 < p.D;
+  __shared__ float red[2][LF * 4 + 1];
+  if (p.colsum != nullptr) {
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) (&red[0][0])[t] = 0.f;
+    __syncthreads();
+  }
+  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.ep_scale != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (f0 + c < p.D) { sc4[c] = p.ep_scale[f0 + c]; sh4[c] = p.ep_shift[f0 + c]; }
+  }
+  float4 cs_s = make_float4(0.f, 0.f, 0.f, 0.f), cs_t = cs_s;
+  float n_s = 0.f, n_t = 0.f;
+  for (int64_t hrow = (int64_t)blockIdx.x * GPB + grp; hrow < p.n_hubs; hrow += (int64_t)gridDim.x * GPB) {
+    const int64_t node = p.hub_rows[hrow];
+    float m = -INFINITY, s = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t v1 = p.seg_ptr[hrow + 1];
+    for (int32_t v0 = p.seg_ptr[hrow]; v0 < v1; v0 += 4) {          // four segments' loads in flight
+      float m2[4], s2[4];
+      float4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + u < v1 ? v0 + u : v1 - 1;
+        m2[u] = v0 + u < v1 ? p.part_ms[2 * v] : -INFINITY;
+        s2[u] = v0 + u < v1 ? p.part_ms[2 * v + 1] : 0.f;
+        b[u] = f0 < p.ldo ? *reinterpret_cast<const float4*>(p.part_acc + v * p.ldo + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float mn = fmaxf(m, m2[u]);
+        const float c1 = (m == mn) ? 1.f : __expf(m - mn), c2 = (m2[u] == mn) ? 1.f : __expf(m2[u] - mn);
+        s = s * c1 + s2[u] * c2;
+        acc.x = acc.x * c1 + b[u].x * c2; acc.y = acc.y * c1 + b[u].y * c2;
+        acc.z = acc.z * c1 + b[u].z * c2; acc.w = acc.w * c1 + b[u].w * c2;
+        m = mn;
+      }
+    }
+    if (f0 < p.ldo) {
+      const float inv = 1.f / (s + 1e-16f);
+      float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      if (p.ep_scale != nullptr) {
+        o.x = fmaf(o.x, sc4[0], sh4[0]); o.y = fmaf(o.y, sc4[1], sh4[1]);
+        o.z = fmaf(o.z, sc4[2], sh4[2]); o.w = fmaf(o.w, sc4[3], sh4[3]);
+      }
+      if (p.ep_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(p.out + node * p.ldo + f0) = o;
+      if (p.mask[node] != 0) { cs_s.x += o.x; cs_s.y += o.y; cs_s.z += o.z; cs_s.w += o.w; n_s += 1.f; }
+      else                   { cs_t.x += o.x; cs_t.y += o.y; cs_t.z += o.z; cs_t.w += o.w; n_t += 1.f; }
+    }
+  }
+  if (p.colsum != nullptr) {      // lanes -> LDS -> one fp64 atomic per (block, column, domain), as in agg_wide_kernel
+    unsafeAtomicAdd(&red[0][f0], cs_s.x); unsafeAtomicAdd(&red[0][f0 + 1], cs_s.y);
+    unsafeAtomicAdd(&red[0][f0 + 2], cs_s.z); unsafeAtomicAdd(&red[0][f0 + 3], cs_s.w);
+    unsafeAtomicAdd(&red[1][f0], cs_t.x); unsafeAtomicAdd(&red[1][f0 + 1], cs_t.y);
+    unsafeAtomicAdd(&red[1][f0 + 2], cs_t.z); unsafeAtomicAdd(&red[1][f0 + 3], cs_t.w);
+    if (lane == 0) { unsafeAtomicAdd(&red[0][LF * 4], n_s); unsafeAtomicAdd(&red[1][LF * 4], n_t); }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) {
+      const int d = t / (LF * 4 + 1), c = t % (LF * 4 + 1);
+      const double sum = (double)red[d][c];
+      if (c == LF * 4) unsafeAtomicAdd(&p.colsum[2 * p.ldo + d], sum);
+      else if (c < p.ldo) unsafeAtomicAdd(&p.colsum[d * p.ldo + c], sum);
+    }
+  }
+}
+
+// interleaved narrow heads: one thread per (hub row, head)
+__global__ __launch_bounds__(256) void hub_merge_heads_kernel(HubMergeParams p) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.n_hubs * p.heads) return;
+  const int64_t hrow = t / p.heads;
+  const int h = (int)(t - hrow * p.heads);
+  const int64_t node = p.hub_rows[hrow];
+  float m = -INFINITY, s = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t v = p.seg_ptr[hrow]; v < p.seg_ptr[hrow + 1]; ++v) {
+    const int64_t e = (int64_t)v * p.heads + h;
+    const float m2 = p.part_ms[2 * e], s2 = p.part_ms[2 * e + 1];
+    const float4 b = *reinterpret_cast<const float4*>(p.part_acc + e * p.ldo);
+    const float mn = fmaxf(m, m2);
+    const float c1 = (m == mn) ? 1.f : __expf(m - mn), c2 = (m2 == mn) ? 1.f : __expf(m2 - mn);
+    s = s * c1 + s2 * c2;
+    acc.x = acc.x * c1 + b.x * c2; acc.y = acc.y * c1 + b.y * c2;
+    acc.z = acc.z * c1 + b.z * c2; acc.w = acc.w * c1 + b.w * c2;
+    m = mn;
+  }
+  const float inv = 1.f / (s + 1e-16f);
+  float4 r = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (p.state_ms != nullptr) {
+    p.state_ms[2 * (node * p.heads + h)] = m;
+    p.state_ms[2 * (node * p.heads + h) + 1] = s;
+  }
+  if (p.ep_relu == 2) {    // log_softmax over the head's D classes (KTGNN.py:435), as in the aggregation kernels
+    float mx = r.x;
+    if (p.D > 1) mx = fmaxf(mx, r.y);
+    if (p.D > 2) mx = fmaxf(mx, r.z);
+    if (p.D > 3) mx = fmaxf(mx, r.w);
+    float se = expf(r.x - mx);
+    if (p.D > 1) se += expf(r.y - mx);
+    if (p.D > 2) se += expf(r.z - mx);
+    if (p.D > 3) se += expf(r.w - mx);
+    const float lse = logf(se);
+    r.x = r.x - mx - lse;
+    r.y = p.D > 1 ? r.y - mx - lse : 0.f;
+    r.z = p.D > 2 ? r.z - mx - lse : 0.f;
+    r.w = p.D > 3 ? r.w - mx - lse : 0.f;
+  }
+  *reinterpret_cast<float4*>(p.out + (node * p.heads + h) * p.ldo) = r;
+}
+
+static int dispatch_aggregate(const AggParams& p, hipStream_t st) {
+  const int32_t D = p.D, heads = p.heads;
+  if (heads == 3 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<3, 4, 4>(p, st);   // KT-GNN's classifier stage
+  if (heads == 2 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<2, 4, 4>(p, st);
+  const int nv = (D + 3) / 4;   // float4 slots per row
+  // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
+  // one sub-group per row with deep unrolling beats edge-parallel sub-groups except for the narrowest rows.
+  if (nv <= 1) return launch<1, 4, 4>(p, st);
+  if (nv <= 2) return launch<2, 2, 4>(p, st);
+  if (nv <= 4) return launch<4, 1, 8>(p, st);
+  if (nv <= 8) return launch<8, 1, 4>(p, st);
+  // wide rows: the VALU-lean kernel (needs max(z, slope*z) == leaky_relu and 32-bit row strides)
+  const bool wide_ok = p.slope >= 0.f && p.slope <= 1.f && (int64_t)heads * p.ldh * 4 < (int64_t)1 << 32;
+  if (wide_ok) {
+    if (nv <= 16) return launch_wide<16, 4>(p, st);
+    if (nv <= 32) return launch_wide<32, 4>(p, st);
+    return launch_wide<64, 4>(p, st);
+  }
+  if (nv <= 16) return launch<16, 1, 8>(p, st);
+  if (nv <= 32) return launch<32, 1, 4>(p, st);
+  return launch<64, 1, 4>(p, st);
+}
+
+// does dispatch_aggregate pick a kernel that understands hub_threshold / vrow_node for this shape?
+static bool hub_capable(int32_t D, int64_t ldh, int64_t ldo, int32_t heads, float slope) {
+  if ((heads == 3 || heads == 2) && D <= 4 && ldh == 4 && ldo == 4) return true;
+  const int nv = (D + 3) / 4;
+  return heads == 1 && nv > 8 && slope >= 0.f && slope <= 1.f && ldh * 4 < (int64_t)1 << 32;
 }
 
 }  // namespace
@@ -937,25 +1132,66 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
     hipError_t e = hipMemsetAsync(tile_queue_opt, 0, 8 * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
   }
-  if (heads == 3 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<3, 4, 4>(p, st);   // KT-GNN's classifier stage
-  if (heads == 2 && D <= 4 && ldh == 4 && ldo == 4) return launch_heads<2, 4, 4>(p, st);
-  const int nv = (D + 3) / 4;   // float4 slots per row
-  // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
-  // one sub-group per row with deep unrolling beats edge-parallel sub-groups except for the narrowest rows.
-  if (nv <= 1) return launch<1, 4, 4>(p, st);
-  if (nv <= 2) return launch<2, 2, 4>(p, st);
-  if (nv <= 4) return launch<4, 1, 8>(p, st);
-  if (nv <= 8) return launch<8, 1, 4>(p, st);
-  // wide rows: the VALU-lean kernel (needs max(z, slope*z) == leaky_relu and 32-bit row strides)
-  const bool wide_ok = negative_slope >= 0.f && negative_slope <= 1.f && (int64_t)heads * ldh * 4 < (int64_t)1 << 32;
-  if (wide_ok) {
-    if (nv <= 16) return launch_wide<16, 4>(p, st);
-    if (nv <= 32) return launch_wide<32, 4>(p, st);
-    return launch_wide<64, 4>(p, st);
+  return dispatch_aggregate(p, st);
+}
+
+extern "C" size_t bgnn_aggregate_hub_workspace_bytes(int64_t n_segments, int32_t heads, int64_t ldo) {
+  const size_t nv = (size_t)(n_segments > 0 ? n_segments : 0), h = (size_t)(heads > 0 ? heads : 1);
+  return bgnn_align_up(sizeof(float) * nv * h * (size_t)(ldo > 0 ? ldo : 0), 256) + bgnn_align_up(sizeof(float) * 2 * nv * h, 256) + 256;
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                                  const float* a_t2s, const float* a_s2t,
+                                                  const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                  int64_t N, int32_t D, float negative_slope, float* out, int64_t ldo,
+                                                  const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                                  float* state_ms_opt, int32_t heads, double* colsum_opt,
+                                                  uint32_t* tile_queue_opt, int32_t hub_threshold, const int32_t* hub_rows,
+                                                  int64_t n_hubs, const int32_t* hub_seg_ptr, const int32_t* seg_bounds,
+                                                  const int32_t* seg_node, int64_t n_segments, void* ws, size_t ws_bytes,
+                                                  void* stream) {
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
+  if (n_hubs > 0 && (!hub_rows || !hub_seg_ptr || !seg_bounds || !seg_node || !ws)) return BGNN_E_NULL;
+  if (N < 0 || D <= 0 || D > 256 || ldh < D || ldo < D || (ldh & 3) || (ldo & 3) || hub_threshold < 2 || n_hubs < 0 || n_segments < n_hubs)
+    return BGNN_E_SHAPE;
+  if (!hub_capable(D, ldh, ldo, heads, negative_slope)) return BGNN_E_SHAPE;
+  if (colsum_opt && heads != 1) return BGNN_E_SHAPE;
+  if (heads > 1 && ep_scale_opt) return BGNN_E_SHAPE;
+  if (ep_relu < 0 || ep_relu > 2 || (ep_relu == 2 && heads == 1)) return BGNN_E_SHAPE;
+  if ((ep_scale_opt == nullptr) != (ep_shift_opt == nullptr)) return BGNN_E_NULL;
+  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || (ws && !bgnn_aligned16(ws))) return BGNN_E_ALIGN;
+  if (n_hubs > 0 && ws_bytes < bgnn_aggregate_hub_workspace_bytes(n_segments, heads, ldo)) return BGNN_E_WORKSPACE;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int part = (state_ms_opt && heads > 1) ? 3 : 0;
+  AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, 0, N, D, negative_slope,
+              out, ldo, nullptr, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part,
+              0, 4};
+  p.hub_threshold = n_hubs > 0 ? hub_threshold : 0;
+  if (tile_queue_opt) {
+    hipError_t e = hipMemsetAsync(tile_queue_opt, 0, 8 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
   }
-  if (nv <= 16) return launch<16, 1, 8>(p, st);
-  if (nv <= 32) return launch<32, 1, 4>(p, st);
-  return launch<64, 1, 4>(p, st);
+  float* part_acc = n_hubs > 0 ? (float*)ws : nullptr;
+  float* part_ms = n_hubs > 0 ? (float*)((char*)ws + bgnn_align_up(sizeof(float) * (size_t)n_segments * (size_t)heads * (size_t)ldo, 256)) : nullptr;
+  if (n_hubs > 0) {                                    // the hub rows' segments ride in the same launch as virtual rows
+    p.vrow_node = seg_node; p.vrow_bounds = seg_bounds; p.n_vrows = n_segments; p.vout = part_acc; p.vms = part_ms;
+  }
+  int rc = dispatch_aggregate(p, st);
+  if (rc || n_hubs == 0) return rc;
+  HubMergeParams mp{hub_rows, hub_seg_ptr, n_hubs, part_acc, part_ms, mask, D, ldo, heads, out, ep_scale_opt, ep_shift_opt,
+                    ep_relu, colsum_opt, part == 3 ? state_ms_opt : nullptr};
+  if (heads > 1) {
+    hipLaunchKernelGGL(hub_merge_heads_kernel, dim3((unsigned)((n_hubs * heads + 255) / 256)), dim3(256), 0, st, mp);
+  } else {
+    const int nvs = (D + 3) / 4;
+    int64_t grid = n_hubs < 2048 ? n_hubs : 2048;
+    if (nvs <= 16) hipLaunchKernelGGL(hub_merge_wide_kernel<16>, dim3((unsigned)((grid + 15) / 16)), dim3(256), 0, st, mp);
+    else if (nvs <= 32) hipLaunchKernelGGL(hub_merge_wide_kernel<32>, dim3((unsigned)((grid + 7) / 8)), dim3(256), 0, st, mp);
+    else hipLaunchKernelGGL(hub_merge_wide_kernel<64>, dim3((unsigned)((grid + 3) / 4)), dim3(256), 0, st, mp);
+  }
+  BGNN_LAUNCH_CHECK();
+  return 0;
 }
 
 #ifdef BGNN_TUNING

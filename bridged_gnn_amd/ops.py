@@ -15,6 +15,11 @@ def pad4(n):
     return (int(n) + 3) // 4 * 4
 
 
+# rows with at least this many in-edges are cut into segments of HUB_SEGMENT edges (AggParams::hub_threshold)
+HUB_THRESHOLD = 192
+HUB_SEGMENT = 64
+
+
 class DstCSR:
     """By-destination CSR of the rewritten edge set: the build's replacement for the cached
     (edge_index1, edge_index2) pair of `KTGNN_no_complement.graph_partition`
@@ -24,6 +29,34 @@ class DstCSR:
         self.rowptr, self.col, self.eperm = rowptr, col, eperm
         self.num_edges, self.num_nodes = int(num_edges), int(num_nodes)
         self._transposed = None
+        self._hubs = {}
+
+    def hub_tables(self, threshold=HUB_THRESHOLD, segment=HUB_SEGMENT):
+        """Rows with >= `threshold` in-edges, cut into segments of <= `segment` edges, built once per graph:
+        None when the graph has no such row, else (hub_rows [nh], hub_seg_ptr [nh+1], seg_bounds [2 nseg] = (begin, end) edge
+        offsets into `col` per segment, seg_node [nseg]), int32 device tensors (see bgnn_adaptedconv_aggregate_hub_f32)."""
+        key = (int(threshold), int(segment))
+        if key not in self._hubs:
+            N = self.num_nodes
+            rp = self.rowptr[:N + 1].long()
+            deg = rp[1:] - rp[:-1]
+            hubs = torch.nonzero(deg >= threshold).reshape(-1)               # one-time sync, like the CSR build itself
+            if hubs.numel() == 0:
+                self._hubs[key] = None
+            else:
+                nseg = (deg[hubs] + segment - 1) // segment                   # segments per hub row
+                seg_ptr = torch.zeros(hubs.numel() + 1, dtype=torch.int64, device=hubs.device)
+                seg_ptr[1:] = torch.cumsum(nseg, 0)
+                total = int(seg_ptr[-1].item())
+                seg_hub = torch.repeat_interleave(torch.arange(hubs.numel(), device=hubs.device), nseg)   # hub index of a segment
+                seg_in_hub = torch.arange(total, device=hubs.device) - seg_ptr[seg_hub]
+                start = rp[hubs][seg_hub] + seg_in_hub * segment
+                end = torch.minimum(start + segment, rp[hubs + 1][seg_hub])
+                # hub rows are not adjacent in `col`, so a segment carries its own (begin, end) pair: v -> bounds[2v], bounds[2v+1]
+                bounds = torch.stack((start, end), dim=1).reshape(-1)
+                self._hubs[key] = (hubs.to(torch.int32).contiguous(), seg_ptr.to(torch.int32).contiguous(),
+                                   bounds.to(torch.int32).contiguous(), hubs[seg_hub].to(torch.int32).contiguous())
+        return self._hubs[key]
 
     def transposed(self):
         """By-SOURCE view of the same edges, built once per graph (training only): (t_rowptr [N+1], t_eid [E'] = position
@@ -376,6 +409,13 @@ def heads_log_softmax_supported(heads, D):
     return heads in (2, 3) and D <= 4
 
 
+def _hub_shape_ok(D, ldh, ldo, heads, slope):
+    """the shapes whose kernels understand hub segments (bgnn.h: bgnn_adaptedconv_aggregate_hub_f32)"""
+    if heads in (2, 3) and D <= 4 and ldh == 4 and ldo == 4:
+        return True
+    return heads == 1 and D > 32 and 0.0 <= slope <= 1.0
+
+
 def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_slope=0.1, n_dst=None,
                           want_alpha=False, ep_scale=None, ep_shift=None, ep_relu=False, out=None,
                           row_begin=0, row_end=None, state_ms=None, part=0, heads=1, colsum=None, log_softmax=False,
@@ -400,6 +440,25 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
     if row_end <= int(row_begin):                    # empty row range (e.g. no boundary rows at world size 1)
         return (out, alpha) if want_alpha else out
+    # graphs with hub rows: segments + merge (bgnn.h).  Whole-graph, single-launch calls of the two hub-aware kernels only.
+    if (not want_alpha and part in (0, 3) and int(row_begin) == 0 and row_end == csr.num_nodes == n_dst and h_t2s.shape[0] == n_dst
+            and (ep_scale is None or heads == 1) and _hub_shape_ok(D, ldh, out.stride(0) // heads, heads, negative_slope)
+            and os.environ.get("BGNN_HUB_ROWS", "1") != "0"):
+        hubs = csr.hub_tables()
+        if hubs is not None:
+            hub_rows, seg_ptr, seg_bounds, seg_node = hubs
+            nseg = int(seg_node.numel())
+            wsb = lib.bgnn_aggregate_hub_workspace_bytes(nseg, heads, out.stride(0) // heads)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            rc = lib.bgnn_adaptedconv_aggregate_hub_f32(
+                L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
+                L.ptr(mask_u8), n_dst, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads,
+                L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0),
+                L.ptr(state_ms) if part == 3 else None, int(heads), L.ptr(colsum),
+                L.ptr(_tile_queue(dev)) if heads == 1 else None, HUB_THRESHOLD, L.ptr(hub_rows), int(hub_rows.numel()),
+                L.ptr(seg_ptr), L.ptr(seg_bounds), L.ptr(seg_node), nseg, L.ptr(ws), wsb, L.stream())
+            L.check(rc, "bgnn_adaptedconv_aggregate_hub_f32")
+            return out
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),

@@ -293,3 +293,98 @@ def test_input_domain_sums_cache_follows_x():
         fresh.load_state_dict(model.state_dict())
         d = fresh(Data(x=x.clone(), edge_index=_t(ei), central_mask=_t(mask)))[:3]
         assert all(close(u, v) for u, v in zip(c, d)) and not close(a[0], c[0])
+
+
+def _hub_graph(n, n_hubs, hub_deg, seed):
+    """random multigraph + `n_hubs` destination rows with ~hub_deg in-edges each (both domains)"""
+    from bridged_gnn_amd import synth
+    ei, mask = synth.random_multigraph(n, 6 * n, frac_src=0.4, n_isolated=2, seed=seed)
+    rng = np.random.default_rng(seed)
+    hubs = rng.choice(n, size=n_hubs, replace=False)
+    extra = np.stack([rng.integers(0, n, size=n_hubs * hub_deg), np.repeat(hubs, hub_deg)])
+    return np.concatenate([ei, extra], axis=1).astype(np.int64), mask, hubs
+
+
+@pytest.mark.parametrize("D,heads", [(128, 1), (64, 1), (2, 3), (4, 2)])
+def test_hub_rows_segments_equal_the_single_walk(D, heads, monkeypatch):
+    """Rows above ops.HUB_THRESHOLD are cut into segments, parked and merged (bgnn_adaptedconv_aggregate_hub_f32): same result
+    as the plain launch (1e-6 of the row scale; the summation order inside a hub row differs), epilogue, column sums and
+    the part-3 softmax state included, and vs the C oracle."""
+    from bridged_gnn_amd import ops
+    from oracle import oracle_c as OC
+    n = 4000
+    ei, mask, hubs = _hub_graph(n, 7, 900, seed=D + heads)
+    csr = ops.build_dst_csr(torch.from_numpy(ei).to(DEV), n)
+    tabs = csr.hub_tables()
+    assert tabs is not None and set(hubs.tolist()) <= set(tabs[0].cpu().tolist())
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu().numpy()
+    assert int(tabs[3].numel()) == int(sum((deg[h] + ops.HUB_SEGMENT - 1) // ops.HUB_SEGMENT for h in tabs[0].cpu().tolist()))
+    g = torch.Generator(device=DEV).manual_seed(D)
+    ld = ops.pad4(D)
+    m8 = torch.from_numpy(mask).to(DEV).to(torch.uint8)
+    t1 = torch.zeros(n, heads * ld, device=DEV); t2 = torch.zeros(n, heads * ld, device=DEV)
+    for h in range(heads):
+        t1[:, h * ld:h * ld + D] = torch.randn(n, D, device=DEV, generator=g)
+        t2[:, h * ld:h * ld + D] = torch.randn(n, D, device=DEV, generator=g)
+    a1 = torch.randn(heads, D, device=DEV, generator=g) * 0.3
+    a2 = torch.randn(heads, D, device=DEV, generator=g) * 0.3
+    kw = {}
+    if heads == 1:
+        a1, a2 = a1[0].contiguous(), a2[0].contiguous()
+        kw = dict(ep_scale=torch.rand(D, device=DEV, generator=g) + 0.5, ep_shift=torch.randn(D, device=DEV, generator=g) * 0.1, ep_relu=True)
+
+    def run():
+        extra = dict(kw)
+        ms = None
+        if heads == 1:
+            extra["colsum"] = torch.zeros(2 * ld + 2, dtype=torch.float64, device=DEV)
+        else:
+            ms = torch.zeros(n, heads, 2, device=DEV)
+            extra.update(log_softmax=True, state_ms=ms, part=3)
+        out = ops.adaptedconv_aggregate(t1, t2, a1, a2, csr, m8, D, 0.1, heads=heads, **extra)
+        return out, extra.get("colsum"), ms
+    out_h, cs_h, ms_h = run()
+    monkeypatch.setenv("BGNN_HUB_ROWS", "0")
+    out_p, cs_p, ms_p = run()
+    monkeypatch.delenv("BGNN_HUB_ROWS")
+    scale = float(out_p.abs().max())
+    assert float((out_h - out_p).abs().max()) <= 2e-6 * max(scale, 1.0)
+    if cs_h is not None:
+        assert torch.allclose(cs_h, cs_p, rtol=1e-6, atol=1e-5)
+        assert torch.equal(cs_h[-2:], cs_p[-2:])
+    if ms_h is not None:
+        # the softmax state of a hub row: same max, sum within rounding
+        assert torch.equal(ms_h[:, :, 0], ms_p[:, :, 0]) and torch.allclose(ms_h[:, :, 1], ms_p[:, :, 1], rtol=1e-5)
+    if heads == 1:                               # vs the C oracle (fp64 truth of the same fp32 tables), without epilogue
+        out_raw = ops.adaptedconv_aggregate(t1, t2, a1, a2, csr, m8, D, 0.1)
+        ref = OC.adaptedconv_aggregate_f64(t1[:, :D].contiguous().cpu().numpy(), t2[:, :D].contiguous().cpu().numpy(), a1.cpu().numpy(),
+                                           a2.cpu().numpy(), csr.rowptr.cpu().numpy(), csr.col.cpu().numpy(), mask, 0.1)
+        assert np.abs(out_raw[:, :D].cpu().numpy() - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1.0)
+
+
+def test_hub_rows_in_the_model_forward_c3_like():
+    """the eval forward and the training step on a graph with hub rows (the Twitter stand-in's 581 source nodes have ~750 in-edges):
+    hub path == plain path within 1e-5, gradients flow (the training aggregation of the three heads takes the hub path too)."""
+    import os
+    from bridged_gnn_amd import synth, utils
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    x, ei, y, m = synth.twitter_standin(seed=0)
+    und = utils.to_undirected(torch.from_numpy(ei).to(DEV), x.shape[0])
+    torch.manual_seed(0)
+    model = KTGNN_no_complement(300, 2, 2, 128, use_bn=True, dim_share=300).to(DEV).eval()
+    data = Data(x=torch.from_numpy(x).to(DEV), edge_index=und, central_mask=torch.from_numpy(m).to(DEV))
+    with torch.no_grad():
+        a = [t.clone() for t in model(data)[:3]]
+        assert model._csr.hub_tables() is not None
+        os.environ["BGNN_HUB_ROWS"] = "0"
+        try:
+            b = [t.clone() for t in model(data)[:3]]
+        finally:
+            del os.environ["BGNN_HUB_ROWS"]
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-5)
+    model.train()
+    lb, lt, lth, _ = model(data)
+    (lb.sum() + lt.sum() + lth.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
