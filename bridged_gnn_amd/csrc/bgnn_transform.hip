@@ -173,6 +173,12 @@ struct GemmParams {
   const float* w2;      // [8][NC]: packed rows of the consumer conv (4 of W_t, 4 of W_s), zero padded
   const float* g2;      // [2][2*NC]: its gate vectors (s2t, t2s), x-half first
   float* raw;           // [N][12]: W_t.a (4) | W_s.a (4) | a.g_s2t | a.g_t2s | 0 | 0   for the activation row a
+  // MODE 0, one head: rows [tail_t2s_begin, tail_s2t_begin) need table 1 (h_t2s) only, rows [tail_s2t_begin, N) table 0 only (the
+  // resident input halo of a partitioned graph: a halo row feeds destinations of one domain).  The waves of the other
+  // table sit a whole tile of such rows out (no MFMAs, no stores): half the matrix work and half the writes for them in the
+  // SAME launch (three launches -- both / t2s-only / s2t-only -- measured slower than doing both tables everywhere).
+  // Both = N: no tail.
+  int64_t tail_t2s_begin, tail_s2t_begin;
 };
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
@@ -606,6 +612,17 @@ __global__ __launch_bounds__(64 * NW) void transform_wreg_kernel(GemmParams p) {
     sstore(cur ^ 1);                                          // tile it+1: registers -> LDS
     gload(min(tile + 2 * (int64_t)gridDim.x, last));          // tile it+2 flies during the MFMA phase
     __builtin_amdgcn_sched_barrier(0);        // keep the loads ABOVE the MFMA chain (the scheduler sinks them to their use)
+    if constexpr (MODE == 0) {
+      // single-table tail rows (GemmParams): a whole tile inside one tail group is skipped by the other table's waves
+      const int64_t tb = tile * BMW + rs * 32, te = tb + 32;
+      const int my_table = (col_base / (int)p.ldh) & 1;
+      const bool tails = p.tail_s2t_begin > 0;                  // (zero-initialised params: no tail)
+      const bool skip = tails && ((my_table == 0 && tb >= p.tail_t2s_begin && te <= p.tail_s2t_begin) || (my_table == 1 && tb >= p.tail_s2t_begin));
+      if (skip) {                               // wave-uniform; the staging above and the barrier below are still shared
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        continue;
+      }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -958,7 +975,7 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
   hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((NC + 2 * n_heads + 3) / 4)), dim3(256), 0, st, Wp, NC, Din, delta, sums, gates,
                      gate_const_opt, n_heads, wd, gc);
   BGNN_LAUNCH_CHECK();
-  GemmParams p;
+  GemmParams p{};
   p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = Wp; p.bias = bias_p; p.wd = wd; p.g = gates; p.gc = gc;
   p.out[0][0] = h_s2t_0; p.out[0][1] = h_t2s_0; p.out[1][0] = h_s2t_1; p.out[1][1] = h_t2s_1;
   p.ldh = ldh; p.row_stride = row_stride; p.NC = NC; p.n_heads = n_heads; p.relu = 0; p.colsum = nullptr; p.col_off = 0;
@@ -970,36 +987,13 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
   }();
   static const bool use_wreg = [] { const char* e = getenv("BGNN_GEMM_WREG"); return !e || atoi(e) != 0; }();
   // Tail rows that need ONE table (the resident input halo of a partitioned graph: a halo row feeds destinations of one
-  // domain): two extra launches over the column range of that table -- half the MFMA work and half the writes for them.
-  // Outside the envelope below the tail rows simply get both tables like every other row.
-  if ((n_tail_t2s || n_tail_s2t) && use_wreg && n_heads == 1 && ldh % 64 == 0 && Din <= 128) {
-    const int64_t n_both = N - n_tail_t2s - n_tail_s2t;
-    const int nct = ldh % 256 == 0 ? 8 : ldh % 128 == 0 ? 4 : 2;
-    const int nw = nct == 2 ? 4 : 8;
-    const int bmw = 32 * (nw / nct);
-    static const bool bf3 = [] { const char* e = getenv("BGNN_GEMM_BF3"); return !e || atoi(e) != 0; }();
-    auto one_table = [&](int64_t r0, int64_t n, int table) {
-      if (n <= 0) return;
-      GemmParams q = p;
-      q.x = x + r0 * ldx; q.mask = mask + r0; q.N = n;
-      q.out[0][0] = h_s2t_0 + r0 * row_stride; q.out[0][1] = h_t2s_0 + r0 * row_stride;
-      q.col_off = table * (int)ldh; q.NC = (table + 1) * (int)ldh;
-      const int64_t ntiles = (n + bmw - 1) / bmw;
-      const int64_t gx = (int64_t)n_cu * (nw == 4 ? 2 : 1);
-      const dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), (unsigned)(ldh / (32 * nct)));
-#define BGNN_WREG1(DK, NCT, NW) do { if (bf3 && NCT >= 4) hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, true, 0>), grid, dim3(64 * NW), 0, st, q); \
-                                      else hipLaunchKernelGGL((transform_wreg_kernel<DK, NCT, NW, false, 0>), grid, dim3(64 * NW), 0, st, q); } while (0)
-#define BGNN_WREG1_DK(NCT, NW) do { if (Din <= 64) BGNN_WREG1(64, NCT, NW); else BGNN_WREG1(128, NCT, NW); } while (0)
-      if (nct == 2) BGNN_WREG1_DK(2, 4); else if (nct == 4) BGNN_WREG1_DK(4, 8); else BGNN_WREG1_DK(8, 8);
-#undef BGNN_WREG1_DK
-#undef BGNN_WREG1
-    };
-    one_table(n_both, n_tail_t2s, 1);
-    one_table(n_both + n_tail_t2s, n_tail_s2t, 0);
-    BGNN_LAUNCH_CHECK();
-    if (n_both == 0) return 0;
-    N = n_both;
-    p.N = n_both;
+  // domain): the W-stationary kernel lets the other table's waves sit those row tiles out (GemmParams::tail_*).  Outside
+  // its envelope the tail rows simply get both tables like every other row.
+  p.tail_t2s_begin = 0; p.tail_s2t_begin = 0;
+  if ((n_tail_t2s || n_tail_s2t) && use_wreg && n_heads == 1 && NC % 64 == 0 && Din <= 128) {
+    p.tail_t2s_begin = N - n_tail_t2s - n_tail_s2t;
+    p.tail_s2t_begin = N - n_tail_s2t;
+    if (p.tail_s2t_begin == 0) p.tail_s2t_begin = 1, p.tail_t2s_begin = p.tail_t2s_begin > 1 ? 1 : p.tail_t2s_begin;   // (rows from 0: keep the "tails on" encoding; a tile never ends at row 0)
   }
   if (use_wreg && NC % 64 == 0 && Din <= 128) {   // (Din = 256 needs 128 weight registers per lane and spills)
     // W-stationary persistent kernel: one 512-thread block per CU, column groups of 32*NCT in grid.y

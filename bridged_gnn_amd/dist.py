@@ -265,7 +265,9 @@ class PartitionedKTGNN:
         # exchange is ~100 MB per rank per forward, more than the rank's whole compute.  Later convs consume activations
         # and keep the per-forward exchange.  False = exchange transformed rows for every conv.
         self.cache_input_halo = bool(cache_input_halo)
-        self.single_table_halo = False
+        # a resident halo row feeds destinations of ONE domain: the transform computes just that table for it (one launch,
+        # the other table's waves sit those row tiles out: GemmParams::tail_*; hidden transform of a rank's share 132 -> 9x us)
+        self.single_table_halo = True
         self._x_ext_key, self._x_ext = None, None
         self._x_sums_key, self._x_sums = None, None
         self.model, self.rank, self.world, self.device, self.group = model, rank, world, device, group
@@ -359,8 +361,6 @@ class PartitionedKTGNN:
                 sums = self._all_reduce(sums)
             self._x_sums, self._x_sums_key = sums, (weakref.ref(x), x._version)
         sums = self._x_sums
-        # (`tail_single=p.n_halo_by_table` would give each halo group only the table it is read from: 397 instead of
-        #  500 MB of traffic, but three launches -- 130 vs 123 us on a rank's share of C4, so one launch does both tables)
         h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums,
                                       tail_single=tuple(p.n_halo_by_table) if self.single_table_halo else (0, 0))
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
