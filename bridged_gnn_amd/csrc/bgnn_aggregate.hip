@@ -578,141 +578,12 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   }
 }
 
-// Narrow multi-head variant (D <= 4, i.e. one float4 per head): ONE lane group walks a destination's in-edges
-// for all HEADS convs at once -- the neighbour id is read once and the HEADS x 16-B pieces of a neighbour row
-// are independent loads, so the per-edge latency chain is shared instead of repeated per head.
-template <int HEADS, int EP, int U>
-__global__ __launch_bounds__(256) void agg_heads_kernel(AggParams p) {
-  constexpr int GPW = 64 / EP, RPB = 4 * GPW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / EP, sub = lane % EP;
-  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
-  bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);    // positions of this XCD's segment sequence (XCD balance)
-  const int64_t rs = (int64_t)HEADS * p.ldh;         // floats between consecutive nodes of a table
-  for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
-    const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
-    if (tile < 0) continue;
-    const int64_t i = p.row_begin + tile * RPB + wave * GPW + g;
-    const bool rvalid = i < p.row_end;
-    const int64_t ic = rvalid ? i : p.row_begin;
-    const bool dom_s = p.mask[ic] != 0;
-    const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
-    const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
-    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
-    float4 a4[HEADS], hi[HEADS], acc[HEADS];
-    float m[HEADS], s[HEADS];
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-      a4[h].x = av[h * p.D];
-      a4[h].y = p.D > 1 ? av[h * p.D + 1] : 0.f;
-      a4[h].z = p.D > 2 ? av[h * p.D + 2] : 0.f;
-      a4[h].w = p.D > 3 ? av[h * p.D + 3] : 0.f;
-      hi[h] = *reinterpret_cast<const float4*>(H + ic * rs + h * p.ldh);
-      acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      m[h] = -INFINITY; s[h] = 0.f;
-    }
-    if (p.mode == 2 && rvalid && sub == 0) {
-#pragma unroll
-      for (int h = 0; h < HEADS; ++h) {
-        m[h] = p.state_ms[2 * (i * HEADS + h)];
-        s[h] = p.state_ms[2 * (i * HEADS + h) + 1];
-        acc[h] = *reinterpret_cast<const float4*>(p.out + (i * HEADS + h) * p.ldo);
-      }
-    }
-    const int32_t niter = (end - beg + EP * U - 1) / (EP * U);
-    for (int32_t it = 0; it < niter; ++it) {
-      int32_t id[U];
-      float4 v[U][HEADS];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int32_t e = beg + it * (EP * U) + sub + u * EP;
-        id[u] = e < end ? p.col[e] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h)
-          v[u][h] = id[u] >= 0 ? *reinterpret_cast<const float4*>(H + (int64_t)id[u] * rs + h * p.ldh) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int h = 0; h < HEADS; ++h) {
-        float lg_[U], cm = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          float t = a4[h].x * leaky(v[u][h].x + hi[h].x, p.slope);
-          t = fmaf(a4[h].y, leaky(v[u][h].y + hi[h].y, p.slope), t);
-          t = fmaf(a4[h].z, leaky(v[u][h].z + hi[h].z, p.slope), t);
-          t = fmaf(a4[h].w, leaky(v[u][h].w + hi[h].w, p.slope), t);
-          lg_[u] = id[u] >= 0 ? t : -INFINITY;
-          cm = fmaxf(cm, lg_[u]);
-        }
-        const float mn = fmaxf(m[h], cm);
-        const float sc = (m[h] == mn) ? 1.f : __expf(m[h] - mn);
-        s[h] *= sc;
-        acc[h].x *= sc; acc[h].y *= sc; acc[h].z *= sc; acc[h].w *= sc;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float pe = (lg_[u] == -INFINITY) ? 0.f : __expf(lg_[u] - mn);
-          s[h] += pe;
-          acc[h].x = fmaf(pe, v[u][h].x, acc[h].x); acc[h].y = fmaf(pe, v[u][h].y, acc[h].y);
-          acc[h].z = fmaf(pe, v[u][h].z, acc[h].z); acc[h].w = fmaf(pe, v[u][h].w, acc[h].w);
-        }
-        m[h] = mn;
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-#pragma unroll
-      for (int off = 1; off < EP; off <<= 1) {
-        const float m2 = __shfl_xor(m[h], off), s2 = __shfl_xor(s[h], off);
-        float4 b;
-        b.x = __shfl_xor(acc[h].x, off); b.y = __shfl_xor(acc[h].y, off);
-        b.z = __shfl_xor(acc[h].z, off); b.w = __shfl_xor(acc[h].w, off);
-        const float mn = fmaxf(m[h], m2);
-        const float c1 = (m[h] == mn) ? 1.f : __expf(m[h] - mn), c2 = (m2 == mn) ? 1.f : __expf(m2 - mn);
-        s[h] = s[h] * c1 + s2 * c2;
-        acc[h].x = acc[h].x * c1 + b.x * c2; acc[h].y = acc[h].y * c1 + b.y * c2;
-        acc[h].z = acc[h].z * c1 + b.z * c2; acc[h].w = acc[h].w * c1 + b.w * c2;
-        m[h] = mn;
-      }
-      if (rvalid && sub == 0) {
-        float* o = p.out + (i * HEADS + h) * p.ldo;
-        if (p.mode == 1 && i >= p.park_begin) {
-          p.state_ms[2 * (i * HEADS + h)] = m[h];
-          p.state_ms[2 * (i * HEADS + h) + 1] = s[h];
-          *reinterpret_cast<float4*>(o) = acc[h];
-        } else {
-          const float inv = 1.f / (s[h] + 1e-16f);
-          float4 r = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
-          if (p.mode == 3) {       // training: the softmax state of the finished row, for the heads backward
-            p.state_ms[2 * (i * HEADS + h)] = m[h];
-            p.state_ms[2 * (i * HEADS + h) + 1] = s[h];
-          }
-          if (p.ep_relu == 2) {    // log_softmax over the head's D classes (KTGNN.py:435), row-local
-            float mx = r.x;
-            if (p.D > 1) mx = fmaxf(mx, r.y);
-            if (p.D > 2) mx = fmaxf(mx, r.z);
-            if (p.D > 3) mx = fmaxf(mx, r.w);
-            float se = expf(r.x - mx);
-            if (p.D > 1) se += expf(r.y - mx);
-            if (p.D > 2) se += expf(r.z - mx);
-            if (p.D > 3) se += expf(r.w - mx);
-            const float lse = logf(se);
-            r.x = r.x - mx - lse;
-            r.y = p.D > 1 ? r.y - mx - lse : 0.f;
-            r.z = p.D > 2 ? r.z - mx - lse : 0.f;
-            r.w = p.D > 3 ? r.w - mx - lse : 0.f;
-          }
-          *reinterpret_cast<float4*>(o) = r;
-        }
-      }
-    }
-  }
-}
-
-// The same walk with one lane per (edge slot, head): lanes lg = sub * HEADS + h of a row's group.  The HEADS lanes of an edge
-// read the neighbour's HEADS consecutive 16-byte pieces -- one cache line per edge instead of HEADS separate line requests
-// from one lane (the narrow gathers are bound by the L1's line-request rate, not by bytes), the neighbour id is a broadcast
-// load, and a lane carries one head's state (fewer registers, more waves).
+// Narrow multi-head variant (D <= 4, i.e. one float4 per head): ONE walk of a destination's in-edges serves all HEADS convs
+// (KT-GNN's classifier stage: clf_base(x), clf_target(x), clf_target(T(x)) share the graph; tables interleaved per node).
+// One lane per (edge slot, head): lanes lg = sub * HEADS + h of a row's group.  The HEADS lanes of an edge read the
+// neighbour's HEADS consecutive 16-byte pieces -- one cache line per edge; a single lane walking all heads (round 1's
+// agg_heads_kernel) issued HEADS separate line requests per edge, and the narrow gathers are bound by the L1's line-request
+// rate, not by bytes (C4: 0.240 -> 0.188 ms).  The neighbour id is a broadcast load, and a lane carries one head's state.
 template <int HEADS, int EP, int U>
 __global__ __launch_bounds__(256) void agg_heads_lanes_kernel(AggParams p) {
   constexpr int GL = EP * HEADS, GPW = 64 / GL, RPB = 4 * GPW;
@@ -848,38 +719,25 @@ inline int tq_chunk_for(int64_t ntiles, int64_t grid) {
   return forced > 0 ? forced : 4;
 }
 
-template <int HEADS, int EP, int U, bool LANES>
-int launch_heads_v(const AggParams& p, hipStream_t st) {
-  constexpr int RPB = LANES ? 4 * (64 / (EP * HEADS)) : 4 * (64 / EP);
+template <int HEADS, int EP, int U>
+int launch_heads(const AggParams& p, hipStream_t st) {
+  // (EP, U) = (2, 4) from a sweep on C4 (three heads): 4/4 0.222, 4/2 0.247, 8/2 0.378, 2/2 0.223, 2/4 0.188, 2/8 0.192, 1/4 0.189,
+  // 1/8 0.184 ms (EP = 1 leaves a long row's whole edge list to one lane triple); tools/heads_fwd_time.py times this launch
+  constexpr int RPB = 4 * (64 / (EP * HEADS));
   static const int cap = [] {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    const hipError_t e = LANES ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_lanes_kernel<HEADS, EP, U>, 256, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_kernel<HEADS, EP, U>, 256, 0);
-    if (e != hipSuccess || per_cu < 1) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_heads_lanes_kernel<HEADS, EP, U>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
     if (per_cu > 8) per_cu = 8;
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
-  const int64_t ntiles = (p.row_end - p.row_begin + (LANES ? p.n_vrows : 0) + RPB - 1) / RPB;
+  const int64_t ntiles = (p.row_end - p.row_begin + p.n_vrows + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
-  if (LANES) hipLaunchKernelGGL((agg_heads_lanes_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((agg_heads_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((agg_heads_lanes_kernel<HEADS, EP, U>), dim3((unsigned)grid), dim3(256), 0, st, p);
   BGNN_LAUNCH_CHECK();
   return 0;
-}
-
-template <int HEADS, int EP, int U>
-int launch_heads(const AggParams& p, hipStream_t st) {
-  // BGNN_HEADS_CFG (tools/heads_fwd_time.py sweep only).  C4, three heads: one lane for all heads (EP 4, U 4) 0.240 ms;
-  // lane per head: EP/U 4/4 0.222, 4/2 0.247, 8/2 0.378, 2/2 0.223, 2/4 0.188, 2/8 0.192, 1/4 0.189, 1/8 0.184 ms
-  // (2/4 kept: EP = 1 leaves a hub row's whole edge list to one lane triple)
-  static const int cfg = [] { const char* e = getenv("BGNN_HEADS_CFG"); return e ? atoi(e) : 0; }();
-  if (cfg == 1 && p.n_vrows == 0 && p.hub_threshold == 0) return launch_heads_v<HEADS, EP, U, false>(p, st);
-  if (cfg == 44) return launch_heads_v<HEADS, 4, 4, true>(p, st);
-  if (cfg == 14) return launch_heads_v<HEADS, 1, 4, true>(p, st);
-  return launch_heads_v<HEADS, 2, 4, true>(p, st);
 }
 
 // Persistent grid = exactly the blocks that are co-resident (occupancy x CUs): a larger grid would
@@ -1072,8 +930,8 @@ __global__ __launch_bounds__(256) void hub_merge_heads_kernel(HubMergeParams p) 
 
 static int dispatch_aggregate(const AggParams& p, hipStream_t st) {
   const int32_t D = p.D, heads = p.heads;
-  if (heads == 3 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<3, 4, 4>(p, st);   // KT-GNN's classifier stage
-  if (heads == 2 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<2, 4, 4>(p, st);
+  if (heads == 3 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<3, 2, 4>(p, st);   // KT-GNN's classifier stage
+  if (heads == 2 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<2, 2, 4>(p, st);
   const int nv = (D + 3) / 4;   // float4 slots per row
   // (LF, EP, U) picked from the tools/tune_agg.py sweep on MI355X (profiles/r01/tune_agg_v2.json):
   // one sub-group per row with deep unrolling beats edge-parallel sub-groups except for the narrowest rows.

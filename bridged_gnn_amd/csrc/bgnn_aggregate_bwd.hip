@@ -692,9 +692,8 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
 
 template <int HEADS>
 int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
-  // (EP, U) from a sweep on C4 (tools/heads_bwd_time.py; env override for that sweep only), both passes together:
-  // lane per head 2/4 0.69, 1/4 0.70, 1/2 0.73, 2/2 0.74, 4/4 0.74, 4/2 0.80 ms (one lane for all heads: 1.33 ms)
-  static const int cfg = [] { const char* e = getenv("BGNN_HEADS_BWD_CFG"); return e ? atoi(e) : 0; }();
+  // (EP, U) = (2, 4) from a sweep on C4, both passes together: lane per head 2/4 0.69, 1/4 0.70, 1/2 0.73, 2/2 0.74, 4/4 0.74,
+  // 4/2 0.80 ms (one lane for all heads: 1.33 ms); tools/heads_bwd_time.py times this pair of launches
 #define BGNN_HB(EPV, UV)                                                                                               \
   do {                                                                                                                 \
     constexpr int RPB = 4 * (64 / (EPV * HEADS));                                                                      \
@@ -707,11 +706,6 @@ int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
     BGNN_LAUNCH_CHECK();                                                                                               \
     return 0;                                                                                                          \
   } while (0)
-  if (cfg == 44) BGNN_HB(4, 4);
-  if (cfg == 42) BGNN_HB(4, 2);
-  if (cfg == 22) BGNN_HB(2, 2);
-  if (cfg == 14) BGNN_HB(1, 4);
-  if (cfg == 12) BGNN_HB(1, 2);
   BGNN_HB(2, 4);
 #undef BGNN_HB
 }

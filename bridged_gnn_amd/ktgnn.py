@@ -200,7 +200,7 @@ class _AggregateFn(torch.autograd.Function):
 
 
 class _AggregateHeadsFn(torch.autograd.Function):
-    """Three narrow convs on one graph (KTGNN.py:432-435 under autograd) in ONE CSR walk forward (`agg_heads_kernel`, the
+    """Three narrow convs on one graph (KTGNN.py:432-435 under autograd) in ONE CSR walk forward (`agg_heads_lanes_kernel`, the
     per-head log_softmax of :435 in its epilogue) and one walk per backward pass (`bgnn_adaptedconv_aggregate_heads_bwd_f32`);
     the forward keeps only the rows' softmax state (24 B per node), no per-edge alpha.
     inputs: `heads` (h_t2s, h_s2t) pairs of [N, 4] tables, then a_t2s / a_s2t as [heads, D] -> log-probs [N, heads, 4]."""

@@ -1,10 +1,5 @@
-"""time the three-head classifier aggregation (forward + backward) on the C4 graph for the (EP, U) variants of the backward"""
-import os, sys, subprocess
-if len(sys.argv) == 1:
-    for cfg in ("24", "44", "42", "22", "14", "12"):
-        env = dict(os.environ, BGNN_HEADS_BWD_CFG=cfg)
-        subprocess.run([sys.executable, __file__, cfg], env=env, check=True)
-    sys.exit(0)
+"""time the three-head classifier aggregation (forward + backward) on the C4 graph"""
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -29,4 +24,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(10): r = ops.adaptedconv_aggregate_heads_bwd(t2s, s2t, a_t, a_s, csr, mask_u8, 2, 3, out, ms, g, True, 0.1)
 e.record(); torch.cuda.synchronize()
-print(f"cfg {sys.argv[1]}: heads backward {s.elapsed_time(e)/10:.3f} ms  checksum {float(r[0].double().sum()):.6e}", flush=True)
+print(f"heads backward {s.elapsed_time(e)/10:.3f} ms  checksum {float(r[0].double().sum()):.6e}", flush=True)

@@ -1,9 +1,5 @@
-"""time the three-head classifier aggregation forward on the C4 graph for the kernel variants (BGNN_HEADS_CFG)"""
-import os, sys, subprocess
-if len(sys.argv) == 1:
-    for cfg in ("1", "0", "44", "14"):
-        subprocess.run([sys.executable, __file__, cfg], env=dict(os.environ, BGNN_HEADS_CFG=cfg), check=True)
-    sys.exit(0)
+"""time the three-head classifier aggregation forward on the C4 graph"""
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -25,4 +21,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(20): ops.adaptedconv_aggregate(t2s, s2t, a_t, a_s, csr, mask_u8, 2, 0.1, heads=3, log_softmax=True, out=out)
 e.record(); torch.cuda.synchronize()
-print(f"cfg {sys.argv[1]}: heads forward {s.elapsed_time(e)/20:.3f} ms  checksum {float(out.double().sum()):.9e}", flush=True)
+print(f"heads forward {s.elapsed_time(e)/20:.3f} ms  checksum {float(out.double().sum()):.9e}", flush=True)
