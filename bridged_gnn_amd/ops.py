@@ -15,8 +15,9 @@ def pad4(n):
     return (int(n) + 3) // 4 * 4
 
 
-# rows with at least this many in-edges are cut into segments of HUB_SEGMENT edges (AggParams::hub_threshold)
-HUB_THRESHOLD = 192
+# rows with at least this many in-edges are cut into segments of HUB_SEGMENT edges (AggParams::hub_threshold); tools/hub_sweep.py:
+# config 3 (128, 64) 0.313 = (192, 64) 0.313, (192, 32) 0.330, (64, 32) 0.366 ms; config 2 (128, 64) 0.144, (192, 64) 0.155, off 0.162 ms
+HUB_THRESHOLD = 128
 HUB_SEGMENT = 64
 
 

@@ -85,7 +85,9 @@ def test_aggregation_backward_exact_on_the_same_tables(D, n):
     (o * torch.from_numpy(w).double()).sum().backward()
     assert _rel(out.detach().cpu().double(), o.detach()) < 1e-6
     assert _rel(g1.grad[:, :D].cpu().double(), t1.grad) < 1e-6 and _rel(g2.grad[:, :D].cpu().double(), t2.grad) < 1e-6
-    assert _rel(ga1.grad.cpu().double(), b1.grad) < 3e-6 and _rel(ga2.grad.cpu().double(), b2.grad) < 3e-6
+    # (the attention vectors' gradients are sums over ALL edges, accumulated with fp32 atomics in an order that changes from run
+    #  to run: 1e-6 typical, 4e-6 seen)
+    assert _rel(ga1.grad.cpu().double(), b1.grad) < 1e-5 and _rel(ga2.grad.cpu().double(), b2.grad) < 1e-5
 
 
 @pytest.mark.parametrize("p,q,n", [(260, 128, 5000), (8, 128, 3333), (36, 4, 1025), (288, 64, 700), (4, 4, 5)])

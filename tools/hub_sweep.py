@@ -6,14 +6,18 @@ from bridged_gnn_amd import ops, synth, utils
 from bridged_gnn_amd.data import Data
 from bridged_gnn_amd.ktgnn import KTGNN_no_complement
 dev = "cuda:0"
-x, ei, y, m = synth.twitter_standin(seed=0)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+if cfg == "c3":
+    x, ei, y, m = synth.twitter_standin(seed=0); feat, hidden = 300, 128
+else:
+    x, ei, y, m = synth.sync_rd_intra(n=10000, feat=128, homophily=0.7, deg=10, k_cross=20, seed=0); feat, hidden = 128, 64
 und = utils.to_undirected(torch.from_numpy(ei).to(dev), x.shape[0])
 data = Data(x=torch.from_numpy(x).to(dev), edge_index=und, central_mask=torch.from_numpy(m).to(dev))
-for thr, seg in ((192, 64), (128, 64), (256, 64), (192, 32), (192, 128), (96, 32), (96, 48), (128, 32), (64, 32), (48, 24)):
+for thr, seg in ((192, 64), (128, 64), (1 << 30, 64), (96, 32), (96, 48), (128, 32), (64, 32), (80, 40), (160, 64)):
     ops.HUB_THRESHOLD, ops.HUB_SEGMENT = thr, seg
     ops.DstCSR.hub_tables.__defaults__ = (thr, seg)
     torch.manual_seed(0)
-    model = KTGNN_no_complement(300, 2, 2, 128, use_bn=True, dim_share=300).to(dev).eval()
+    model = KTGNN_no_complement(feat, 2, 2, hidden, use_bn=True, dim_share=feat).to(dev).eval()
     with torch.no_grad():
         run = model.graphed(data)
         for _ in range(5): run()
