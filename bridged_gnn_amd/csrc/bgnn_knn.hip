@@ -352,6 +352,17 @@ __global__ void init_shortlists_kernel(int32_t* __restrict__ sl_idx, int64_t n_i
   if (i < n_tau) sl_tau[i] = -INFINITY;
 }
 
+// the same for the first *count rows only (the precise pass's lists are indexed by the position in the list of unproven rows:
+// 179 MB of stores for C5 where that list is empty)
+__global__ void init_shortlists_rows_kernel(int32_t* __restrict__ sl_idx, int64_t per_row_idx, float* __restrict__ sl_tau,
+                                            int64_t per_row_tau, const int32_t* __restrict__ count) {
+  const int64_t rows = *count;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    for (int64_t t = threadIdx.x; t < per_row_idx; t += blockDim.x) sl_idx[r * per_row_idx + t] = -1;
+    for (int64_t t = threadIdx.x; t < per_row_tau; t += blockDim.x) sl_tau[r * per_row_tau + t] = -INFINITY;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1, cosine.  scores = cand tile (A operand, 32 x d, through LDS) . query block^T (B operand, d x 32, registers) on
 // v_mfma_f32_32x32x16_bf16, so that after the MFMA chain EACH LANE HOLDS 16 SCORES OF ONE QUERY -> one threshold register
@@ -1132,7 +1143,9 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   if (fast_nprod != 3) {
     const int kp2 = geom_precise(k).kp;
     P1Params p{w.qh, w.qm, w.ch, w.cm, Nq, Nc, w.fail1, w.counts, 0, MAX_SLOTS, w.sl2_score, w.sl2_idx, w.sl2_tau, eps, k, 0, 0, nullptr, 0, 0};
-    if ((rc = init_shortlists(w.sl2_idx, Nq * MAX_SLOTS * (int64_t)kp2, w.sl2_tau, Nq * MAX_SLOTS, st))) return rc;
+    hipLaunchKernelGGL(init_shortlists_rows_kernel, dim3(1024), dim3(256), 0, st, w.sl2_idx, (int64_t)MAX_SLOTS * kp2, w.sl2_tau,
+                       (int64_t)MAX_SLOTS, w.counts);
+    BGNN_LAUNCH_CHECK();
     if ((rc = pass1_any(d, 3, k, p, nullptr, nullptr, st))) return rc;
     RefineParams rp{Nq, w.fail1, w.counts, k, MAX_SLOTS * kp2, kp2, MAX_SLOTS, w.sl2_score, w.sl2_idx, w.sl2_tau, eps, 3, 0.0, 0.0,
                     apply_sigmoid, idx_out, val_out, w.fail2, w.counts + 1};
