@@ -152,6 +152,14 @@ struct PullParams {
   unsigned int* queue;   // [16] per-XCD dynamic tile counters (pass A: 0..7, pass B: 8..15), zeroed per call
   float* dstside;        // [N][ldh]
   float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
+  // Hub rows (wide kernels; the forward's scheme, bgnn_aggregate.hip AggParams): a row is walked by one lane group, so a row of
+  // ~750 edges (the Twitter_Graph stand-in's source nodes) is a chain of ~190 dependent steps.  Rows with >= hub_threshold edges
+  // are skipped as rows and walked as <= 64-edge segments that ride behind the real rows of the same launch; a segment leaves
+  // its partial row sums in scratch and a merge launch adds them in a fixed order (deterministic like the rest).  Pass A
+  // segments destinations by in-degree (d_*), pass B sources by out-degree (s_*, offsets into the by-source arrays).
+  int32_t hub_threshold;
+  const int32_t* d_vnode; const int32_t* d_vbounds; int64_t d_nv; float* d_vpart;                 // [d_nv][ldh]
+  const int32_t* s_vnode; const int32_t* s_vbounds; int64_t s_nv; float* s_vpartS; float* s_vpartT;   // [s_nv][ldh] each
 };
 
 template <int LF>
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
   const bool fvalid = f0 < p.D;
   const int f0c = fvalid ? f0 : 0;
   float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;          // da partials per domain
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  const int64_t ntiles = (p.N + p.d_nv + RPB - 1) / RPB;     // real rows, then the hub rows' segments
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
   __shared__ unsigned int dyn_tile;
   const int64_t xbase = tr.begin - (blockIdx.x / 8);
@@ -184,13 +192,20 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
     if (tile >= tr.end) break;
     const int64_t gt = bgnn::xcd_tile_of(tile, ntiles);     // `tile` is a position in the XCD's sequence
     if (gt < 0) continue;
-    const int64_t i = gt * RPB + wave * GPW + g;
-    const bool rvalid = i < p.N;
-    const int64_t ic = rvalid ? i : 0;
+    const int64_t i0 = gt * RPB + wave * GPW + g;
+    const bool in_range = i0 < p.N + p.d_nv;
+    const bool virt = in_range && i0 >= p.N;                   // a segment of a hub destination
+    const int64_t vix = virt ? i0 - p.N : 0;
+    const int64_t i = virt ? (int64_t)p.d_vnode[vix] : i0;
+    const int64_t ic = in_range ? i : 0;
     const bool dom_s = p.mask[ic] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
-    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    int32_t beg = in_range ? (virt ? p.d_vbounds[2 * vix] : p.rowptr[ic]) : 0;
+    int32_t end = in_range ? (virt ? p.d_vbounds[2 * vix + 1] : p.rowptr[ic + 1]) : 0;
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;
+    const bool rvalid = in_range && !hub;
+    if (hub) { beg = 0; end = 0; }
     float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), a4 = gi, oi = gi;
     const float4 hi = *reinterpret_cast<const float4*>(H + ic * p.ldh + f0c);
     if (fvalid) {
@@ -247,7 +262,8 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
         }
       }
     }
-    if (rvalid && f0 < p.ldh) *reinterpret_cast<float4*>(p.dstside + i * p.ldh + f0) = fvalid ? accd : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rvalid && f0 < p.ldh)
+      *reinterpret_cast<float4*>((virt ? p.d_vpart + vix * p.ldh : p.dstside + i * p.ldh) + f0) = fvalid ? accd : make_float4(0.f, 0.f, 0.f, 0.f);
     if (rvalid && fvalid) {
       if (dom_s) { accS.x += accz.x; accS.y += accz.y; accS.z += accz.z; accS.w += accz.w; }
       else       { accT.x += accz.x; accT.y += accz.y; accT.z += accz.z; accT.w += accz.w; }
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
     aS.x = p.a_t2s[f0]; aS.y = f0 + 1 < p.D ? p.a_t2s[f0 + 1] : 0.f; aS.z = f0 + 2 < p.D ? p.a_t2s[f0 + 2] : 0.f; aS.w = f0 + 3 < p.D ? p.a_t2s[f0 + 3] : 0.f;
     aT.x = p.a_s2t[f0]; aT.y = f0 + 1 < p.D ? p.a_s2t[f0 + 1] : 0.f; aT.z = f0 + 2 < p.D ? p.a_s2t[f0 + 2] : 0.f; aT.w = f0 + 3 < p.D ? p.a_s2t[f0 + 3] : 0.f;
   }
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  const int64_t ntiles = (p.N + p.s_nv + RPB - 1) / RPB;     // real rows, then the hub sources' segments
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);   // positions of this XCD's segment sequence (XCD balance)
   __shared__ unsigned int dyn_tile;
   const int64_t xbase = tr.begin - (blockIdx.x / 8);
@@ -299,10 +315,17 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
     if (tile >= tr.end) break;
     const int64_t gt = bgnn::xcd_tile_of(tile, ntiles);     // `tile` is a position in the XCD's sequence
     if (gt < 0) continue;
-    const int64_t j = gt * RPB + wave * GPW + g;
-    const bool rvalid = j < p.N;
-    const int64_t jc = rvalid ? j : 0;
-    const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
+    const int64_t j0 = gt * RPB + wave * GPW + g;
+    const bool in_range = j0 < p.N + p.s_nv;
+    const bool virt = in_range && j0 >= p.N;                   // a segment of a hub source
+    const int64_t vix = virt ? j0 - p.N : 0;
+    const int64_t j = virt ? (int64_t)p.s_vnode[vix] : j0;
+    const int64_t jc = in_range ? j : 0;
+    int32_t beg = in_range ? (virt ? p.s_vbounds[2 * vix] : p.t_rowptr[jc]) : 0;
+    int32_t end = in_range ? (virt ? p.s_vbounds[2 * vix + 1] : p.t_rowptr[jc + 1]) : 0;
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;
+    const bool rvalid = in_range && !hub;
+    if (hub) { beg = 0; end = 0; }
     float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
     const int32_t niter = (end - beg + U - 1) / U;
     int32_t ne[U], ni[U];
@@ -343,7 +366,11 @@ __global__ __launch_bounds__(256) void agg_bwd_src_kernel(PullParams p) {
         else    { accT.x += v.x; accT.y += v.y; accT.z += v.z; accT.w += v.w; }
       }
     }
-    if (rvalid && f0 < p.ldh) {
+    if (virt && f0 < p.ldh) {                                   // a segment: its partial sums, merged afterwards
+      if (!fvalid) { accS = make_float4(0.f, 0.f, 0.f, 0.f); accT = accS; }
+      *reinterpret_cast<float4*>(p.s_vpartS + vix * p.ldh + f0) = accS;
+      *reinterpret_cast<float4*>(p.s_vpartT + vix * p.ldh + f0) = accT;
+    } else if (rvalid && f0 < p.ldh) {
       const bool dom_j = p.mask[j] != 0;
       const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * p.ldh + f0);
       if (!fvalid) { accS = make_float4(0.f, 0.f, 0.f, 0.f); accT = accS; }
@@ -710,8 +737,48 @@ int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
 #undef BGNN_HB
 }
 
+// merges of the hub segments' partial rows (fixed order).  One thread per float4 of a hub row.
+struct PullMergeParams {
+  const int32_t* hub_rows; const int32_t* seg_ptr; int64_t n_hubs; int64_t ldh;
+  const float* partA; const float* partB;      // pass A: partA = d_vpart; pass B: partA / partB = s_vpartS / s_vpartT
+  const uint8_t* mask; float* dstside; float* dh_t2s; float* dh_s2t;
+};
+__global__ __launch_bounds__(256) void pull_merge_dst_kernel(PullMergeParams p) {
+  const int64_t c4n = p.ldh / 4, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.n_hubs * c4n) return;
+  const int64_t h = t / c4n, f0 = (t - h * c4n) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t v = p.seg_ptr[h]; v < p.seg_ptr[h + 1]; ++v) {
+    const float4 b = *reinterpret_cast<const float4*>(p.partA + (int64_t)v * p.ldh + f0);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *reinterpret_cast<float4*>(p.dstside + (int64_t)p.hub_rows[h] * p.ldh + f0) = a;
+}
+__global__ __launch_bounds__(256) void pull_merge_src_kernel(PullMergeParams p) {
+  const int64_t c4n = p.ldh / 4, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.n_hubs * c4n) return;
+  const int64_t h = t / c4n, f0 = (t - h * c4n) * 4;
+  const int64_t j = p.hub_rows[h];
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+  for (int32_t v = p.seg_ptr[h]; v < p.seg_ptr[h + 1]; ++v) {
+    const float4 b = *reinterpret_cast<const float4*>(p.partA + (int64_t)v * p.ldh + f0);
+    const float4 d = *reinterpret_cast<const float4*>(p.partB + (int64_t)v * p.ldh + f0);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w;
+  }
+  const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * p.ldh + f0);
+  if (p.mask[j] != 0) { a.x += ds4.x; a.y += ds4.y; a.z += ds4.z; a.w += ds4.w; }
+  else                { c.x += ds4.x; c.y += ds4.y; c.z += ds4.z; c.w += ds4.w; }
+  *reinterpret_cast<float4*>(p.dh_t2s + j * p.ldh + f0) = a;
+  *reinterpret_cast<float4*>(p.dh_s2t + j * p.ldh + f0) = c;
+}
+struct PullHubs {        // host side of the hub tables (device pointers)
+  const int32_t* d_rows; const int32_t* d_seg_ptr; int64_t d_nh;
+  const int32_t* s_rows; const int32_t* s_seg_ptr; int64_t s_nh;
+};
+
 template <int LF>
-int launch_pull(const PullParams& p, hipStream_t st) {
+int launch_pull(const PullParams& p, hipStream_t st, const PullHubs* hubs = nullptr) {
   constexpr int RPB = 4 * (64 / LF);
   static const int cap = [] {
     int a = 0, b = 0, dev = 0;
@@ -723,13 +790,24 @@ int launch_pull(const PullParams& p, hipStream_t st) {
     if (per_cu > 8) per_cu = 8;
     return per_cu * prop.multiProcessorCount / 8 * 8;
   }();
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  const int64_t nmax = p.N + (p.d_nv > p.s_nv ? p.d_nv : p.s_nv);
+  const int64_t ntiles = (nmax + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
   hipLaunchKernelGGL((agg_bwd_dst_kernel<LF>), dim3((unsigned)grid), dim3(256), 0, st, p);
   BGNN_LAUNCH_CHECK();
+  if (hubs && hubs->d_nh > 0) {            // the hub destinations' dstside rows, before pass B reads them
+    PullMergeParams m{hubs->d_rows, hubs->d_seg_ptr, hubs->d_nh, p.ldh, p.d_vpart, nullptr, p.mask, p.dstside, nullptr, nullptr};
+    hipLaunchKernelGGL(pull_merge_dst_kernel, dim3((unsigned)((hubs->d_nh * (p.ldh / 4) + 255) / 256)), dim3(256), 0, st, m);
+    BGNN_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL((agg_bwd_src_kernel<LF>), dim3((unsigned)grid), dim3(256), 0, st, p);
   BGNN_LAUNCH_CHECK();
+  if (hubs && hubs->s_nh > 0) {
+    PullMergeParams m{hubs->s_rows, hubs->s_seg_ptr, hubs->s_nh, p.ldh, p.s_vpartS, p.s_vpartT, p.mask, p.dstside, p.dh_t2s, p.dh_s2t};
+    hipLaunchKernelGGL(pull_merge_src_kernel, dim3((unsigned)((hubs->s_nh * (p.ldh / 4) + 255) / 256)), dim3(256), 0, st, m);
+    BGNN_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -765,6 +843,47 @@ extern "C" size_t bgnn_aggregate_bwd_pull_workspace_bytes(int64_t N, int64_t E, 
   return (size_t)32 * (size_t)(E > 0 ? E : 0) + sizeof(float) * (size_t)(N > 0 ? N : 0) * (size_t)(ldh > 0 ? ldh : 0) + 1024;
 }
 
+static int pull_impl(const float* h_t2s, const float* h_s2t, int64_t ldh, const float* a_t2s, const float* a_s2t,
+                     const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                     const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                     int64_t N, int64_t E, int32_t D, float negative_slope, const float* out, int64_t ldo, const float* alpha,
+                     const float* grad_out, int64_t ldg, float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                     int32_t hub_threshold, const PullHubs* hubs, const int32_t* d_vbounds, const int32_t* d_vnode, int64_t d_nv,
+                     const int32_t* s_vbounds, const int32_t* s_vnode, int64_t s_nv, void* ws, size_t ws_bytes, void* stream) {
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_eid || !t_dst || !out || !alpha ||
+      !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
+    return BGNN_E_NULL;
+  const bool narrow = D >= 1 && D <= 4 && ldh == 4 && ldo == 4 && ldg == 4;
+  if (N < 0 || E < 0 || D < 1 || D > 128 || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
+  if (hubs && (narrow || hub_threshold < 2 || d_nv < 0 || s_nv < 0)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
+      !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
+    return BGNN_E_ALIGN;
+  const size_t base_bytes = bgnn_aggregate_bwd_pull_workspace_bytes(N, E, ldh);
+  const size_t seg_bytes = hubs ? bgnn_align_up(sizeof(float) * (size_t)ldh * (size_t)(d_nv + 2 * s_nv), 256) + 256 : 0;
+  if (ws_bytes < base_bytes + seg_bytes) return BGNN_E_WORKSPACE;
+  if (N == 0) return 0;
+  uint4* rec = (uint4*)ws;
+  float* dstside = (float*)((char*)ws + bgnn_align_up((size_t)32 * (size_t)E, 256));
+  unsigned int* queue = (unsigned int*)((char*)dstside + bgnn_align_up(sizeof(float) * (size_t)N * (size_t)ldh, 256));
+  PullParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, ldo, alpha, grad_out, ldg,
+               t_rowptr, t_eid, t_dst, rec, queue, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
+  if (hubs) {
+    float* seg = (float*)((char*)ws + bgnn_align_up(base_bytes, 256));
+    p.hub_threshold = hub_threshold;
+    p.d_vnode = d_vnode; p.d_vbounds = d_vbounds; p.d_nv = d_nv; p.d_vpart = seg;
+    p.s_vnode = s_vnode; p.s_vbounds = s_vbounds; p.s_nv = s_nv; p.s_vpartS = seg + (size_t)d_nv * ldh; p.s_vpartT = seg + (size_t)(d_nv + s_nv) * ldh;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (narrow) return launch_pull_narrow(p, st);
+  const int nv = (D + 3) / 4;
+  if (nv <= 2) return launch_pull<2>(p, st, hubs);
+  if (nv <= 4) return launch_pull<4>(p, st, hubs);
+  if (nv <= 8) return launch_pull<8>(p, st, hubs);
+  return nv <= 16 ? launch_pull<16>(p, st, hubs) : launch_pull<32>(p, st, hubs);
+}
+
 extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                                        const float* a_t2s, const float* a_s2t,
                                                        const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
@@ -774,29 +893,40 @@ extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const
                                                        const float* grad_out, int64_t ldg,
                                                        float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
                                                        void* ws, size_t ws_bytes, void* stream) {
-  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_eid || !t_dst || !out || !alpha ||
-      !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
+  return pull_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, t_rowptr, t_eid, t_dst, N, E, D, negative_slope, out, ldo,
+                   alpha, grad_out, ldg, dh_t2s, dh_s2t, da_t2s, da_s2t, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                   ws, ws_bytes, stream);
+}
+
+extern "C" size_t bgnn_aggregate_bwd_pull_hub_workspace_bytes(int64_t N, int64_t E, int64_t ldh, int64_t d_segments, int64_t s_segments) {
+  const size_t nseg = (size_t)(d_segments > 0 ? d_segments : 0) + 2 * (size_t)(s_segments > 0 ? s_segments : 0);
+  return bgnn_align_up(bgnn_aggregate_bwd_pull_workspace_bytes(N, E, ldh), 256) +
+         bgnn_align_up(sizeof(float) * (size_t)(ldh > 0 ? ldh : 0) * nseg, 256) + 512;
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_bwd_pull_hub_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                                           const float* a_t2s, const float* a_s2t,
+                                                           const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                           const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                                                           int64_t N, int64_t E, int32_t D, float negative_slope,
+                                                           const float* out, int64_t ldo, const float* alpha,
+                                                           const float* grad_out, int64_t ldg,
+                                                           float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                                           int32_t hub_threshold,
+                                                           const int32_t* d_hub_rows, int64_t d_n_hubs, const int32_t* d_hub_seg_ptr,
+                                                           const int32_t* d_seg_bounds, const int32_t* d_seg_node, int64_t d_n_segments,
+                                                           const int32_t* s_hub_rows, int64_t s_n_hubs, const int32_t* s_hub_seg_ptr,
+                                                           const int32_t* s_seg_bounds, const int32_t* s_seg_node, int64_t s_n_segments,
+                                                           void* ws, size_t ws_bytes, void* stream) {
+  if (d_n_hubs < 0 || s_n_hubs < 0 || d_n_segments < d_n_hubs || s_n_segments < s_n_hubs) return BGNN_E_SHAPE;
+  if ((d_n_hubs > 0 && (!d_hub_rows || !d_hub_seg_ptr || !d_seg_bounds || !d_seg_node)) ||
+      (s_n_hubs > 0 && (!s_hub_rows || !s_hub_seg_ptr || !s_seg_bounds || !s_seg_node)))
     return BGNN_E_NULL;
-  const bool narrow = D >= 1 && D <= 4 && ldh == 4 && ldo == 4 && ldg == 4;
-  if (N < 0 || E < 0 || D < 1 || D > 128 || ldh < D || ldo < D || ldg < D || (ldh & 3) || (ldo & 3) || (ldg & 3)) return BGNN_E_SHAPE;
-  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
-      !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
-    return BGNN_E_ALIGN;
-  if (ws_bytes < bgnn_aggregate_bwd_pull_workspace_bytes(N, E, ldh)) return BGNN_E_WORKSPACE;
-  if (N == 0) return 0;
-  uint4* rec = (uint4*)ws;
-  float* dstside = (float*)((char*)ws + bgnn_align_up((size_t)32 * (size_t)E, 256));
-  unsigned int* queue = (unsigned int*)((char*)dstside + bgnn_align_up(sizeof(float) * (size_t)N * (size_t)ldh, 256));
-  PullParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, ldo, alpha, grad_out, ldg,
-               t_rowptr, t_eid, t_dst, rec, queue, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
-  if (narrow) return launch_pull_narrow(p, st);
-  const int nv = (D + 3) / 4;
-  if (nv <= 2) return launch_pull<2>(p, st);
-  if (nv <= 4) return launch_pull<4>(p, st);
-  if (nv <= 8) return launch_pull<8>(p, st);
-  return nv <= 16 ? launch_pull<16>(p, st) : launch_pull<32>(p, st);
+  PullHubs hubs{d_hub_rows, d_hub_seg_ptr, d_n_hubs, s_hub_rows, s_hub_seg_ptr, s_n_hubs};
+  return pull_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, t_rowptr, t_eid, t_dst, N, E, D, negative_slope, out, ldo,
+                   alpha, grad_out, ldg, dh_t2s, dh_s2t, da_t2s, da_s2t, hub_threshold, &hubs,
+                   d_seg_bounds, d_seg_node, d_n_hubs > 0 ? d_n_segments : 0, s_seg_bounds, s_seg_node, s_n_hubs > 0 ? s_n_segments : 0,
+                   ws, ws_bytes, stream);
 }
 
 extern "C" size_t bgnn_aggregate_heads_bwd_workspace_bytes(int64_t N, int64_t E, int32_t heads) {

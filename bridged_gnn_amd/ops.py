@@ -32,31 +32,40 @@ class DstCSR:
         self._transposed = None
         self._hubs = {}
 
+    @staticmethod
+    def _hub_tables_of(rowptr, N, threshold, segment):
+        rp = rowptr[:N + 1].long()
+        deg = rp[1:] - rp[:-1]
+        hubs = torch.nonzero(deg >= threshold).reshape(-1)               # one-time sync, like the CSR build itself
+        if hubs.numel() == 0:
+            return None
+        nseg = (deg[hubs] + segment - 1) // segment                       # segments per hub row
+        seg_ptr = torch.zeros(hubs.numel() + 1, dtype=torch.int64, device=hubs.device)
+        seg_ptr[1:] = torch.cumsum(nseg, 0)
+        total = int(seg_ptr[-1].item())
+        seg_hub = torch.repeat_interleave(torch.arange(hubs.numel(), device=hubs.device), nseg)   # hub index of a segment
+        seg_in_hub = torch.arange(total, device=hubs.device) - seg_ptr[seg_hub]
+        start = rp[hubs][seg_hub] + seg_in_hub * segment
+        end = torch.minimum(start + segment, rp[hubs + 1][seg_hub])
+        # hub rows are not adjacent in the edge arrays, so a segment carries its own (begin, end) pair: v -> bounds[2v], bounds[2v+1]
+        bounds = torch.stack((start, end), dim=1).reshape(-1)
+        return (hubs.to(torch.int32).contiguous(), seg_ptr.to(torch.int32).contiguous(),
+                bounds.to(torch.int32).contiguous(), hubs[seg_hub].to(torch.int32).contiguous())
+
     def hub_tables(self, threshold=HUB_THRESHOLD, segment=HUB_SEGMENT):
         """Rows with >= `threshold` in-edges, cut into segments of <= `segment` edges, built once per graph:
         None when the graph has no such row, else (hub_rows [nh], hub_seg_ptr [nh+1], seg_bounds [2 nseg] = (begin, end) edge
         offsets into `col` per segment, seg_node [nseg]), int32 device tensors (see bgnn_adaptedconv_aggregate_hub_f32)."""
         key = (int(threshold), int(segment))
         if key not in self._hubs:
-            N = self.num_nodes
-            rp = self.rowptr[:N + 1].long()
-            deg = rp[1:] - rp[:-1]
-            hubs = torch.nonzero(deg >= threshold).reshape(-1)               # one-time sync, like the CSR build itself
-            if hubs.numel() == 0:
-                self._hubs[key] = None
-            else:
-                nseg = (deg[hubs] + segment - 1) // segment                   # segments per hub row
-                seg_ptr = torch.zeros(hubs.numel() + 1, dtype=torch.int64, device=hubs.device)
-                seg_ptr[1:] = torch.cumsum(nseg, 0)
-                total = int(seg_ptr[-1].item())
-                seg_hub = torch.repeat_interleave(torch.arange(hubs.numel(), device=hubs.device), nseg)   # hub index of a segment
-                seg_in_hub = torch.arange(total, device=hubs.device) - seg_ptr[seg_hub]
-                start = rp[hubs][seg_hub] + seg_in_hub * segment
-                end = torch.minimum(start + segment, rp[hubs + 1][seg_hub])
-                # hub rows are not adjacent in `col`, so a segment carries its own (begin, end) pair: v -> bounds[2v], bounds[2v+1]
-                bounds = torch.stack((start, end), dim=1).reshape(-1)
-                self._hubs[key] = (hubs.to(torch.int32).contiguous(), seg_ptr.to(torch.int32).contiguous(),
-                                   bounds.to(torch.int32).contiguous(), hubs[seg_hub].to(torch.int32).contiguous())
+            self._hubs[key] = DstCSR._hub_tables_of(self.rowptr, self.num_nodes, threshold, segment)
+        return self._hubs[key]
+
+    def transposed_hub_tables(self, threshold=HUB_THRESHOLD, segment=HUB_SEGMENT):
+        """the same over the by-SOURCE view (`transposed()`): sources with >= `threshold` out-edges; offsets into t_eid / t_dst"""
+        key = ("t", int(threshold), int(segment))
+        if key not in self._hubs:
+            self._hubs[key] = DstCSR._hub_tables_of(self.transposed()[0], self.num_nodes, threshold, segment)
         return self._hubs[key]
 
     def transposed(self):
@@ -483,6 +492,26 @@ def adaptedconv_aggregate_bwd(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, out, 
         # D > 128 and for row ranges
         t_rowptr, t_eid, t_dst = csr.transposed()
         dh_t2s, dh_s2t = torch.empty_like(h_t2s), torch.empty_like(h_s2t)
+        narrow = D <= 4 and h_t2s.stride(0) == 4 and out.stride(0) == 4 and grad_out.stride(0) == 4
+        dh_, sh_ = (csr.hub_tables(), csr.transposed_hub_tables()) if (not narrow and os.environ.get("BGNN_HUB_ROWS", "1") != "0") else (None, None)
+        if dh_ is not None or sh_ is not None:      # graphs with hub rows: segments + merge (bgnn.h)
+            none4 = (None, None, None, None)
+            d_rows, d_ptr, d_bounds, d_node = dh_ if dh_ is not None else none4
+            s_rows, s_ptr, s_bounds, s_node = sh_ if sh_ is not None else none4
+            nd = 0 if dh_ is None else int(d_node.numel())
+            ns = 0 if sh_ is None else int(s_node.numel())
+            wsb = lib.bgnn_aggregate_bwd_pull_hub_workspace_bytes(csr.num_nodes, csr.num_edges, h_t2s.stride(0), nd, ns)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            rc = lib.bgnn_adaptedconv_aggregate_bwd_pull_hub_f32(
+                L.ptr(h_t2s), L.ptr(h_s2t), h_t2s.stride(0), L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
+                L.ptr(mask_u8), L.ptr(t_rowptr), L.ptr(t_eid), L.ptr(t_dst), csr.num_nodes, csr.num_edges, D, float(negative_slope),
+                L.ptr(out), out.stride(0), L.ptr(alpha), L.ptr(grad_out), grad_out.stride(0),
+                L.ptr(dh_t2s), L.ptr(dh_s2t), L.ptr(da_t2s), L.ptr(da_s2t), HUB_THRESHOLD,
+                L.ptr(d_rows), 0 if dh_ is None else int(d_rows.numel()), L.ptr(d_ptr), L.ptr(d_bounds), L.ptr(d_node), nd,
+                L.ptr(s_rows), 0 if sh_ is None else int(s_rows.numel()), L.ptr(s_ptr), L.ptr(s_bounds), L.ptr(s_node), ns,
+                L.ptr(ws), wsb, L.stream())
+            L.check(rc, "bgnn_adaptedconv_aggregate_bwd_pull_hub_f32")
+            return dh_t2s, dh_s2t, da_t2s, da_s2t
         wsb = lib.bgnn_aggregate_bwd_pull_workspace_bytes(csr.num_nodes, csr.num_edges, h_t2s.stride(0))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = lib.bgnn_adaptedconv_aggregate_bwd_pull_f32(

@@ -276,6 +276,28 @@ int bgnn_adaptedconv_aggregate_bwd_pull_f32(const float* h_t2s, const float* h_s
                                             float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
                                             void* ws, size_t ws_bytes, void* stream);
 
+/* The same pull-form backward for graphs with hub rows (wide rows only: not the ldh = 4 narrow form).  Pass A walks destinations,
+ * pass B sources: a destination with >= hub_threshold in-edges / a source with that many out-edges is skipped as a row and walked
+ * as segments -- d_* tables over `rowptr` / `col`, s_* tables over the by-source arrays, both in the layout of
+ * bgnn_adaptedconv_aggregate_hub_f32 (hub_rows, hub_seg_ptr, seg_bounds = (begin, end) pairs, seg_node) -- that ride behind the real
+ * rows of the same launch and leave partial row sums, merged in a fixed order (deterministic like the plain form).
+ * ws: bgnn_aggregate_bwd_pull_hub_workspace_bytes(N, E', ldh, d_n_segments, s_n_segments). */
+size_t bgnn_aggregate_bwd_pull_hub_workspace_bytes(int64_t N, int64_t E, int64_t ldh, int64_t d_segments, int64_t s_segments);
+int bgnn_adaptedconv_aggregate_bwd_pull_hub_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                                const float* a_t2s, const float* a_s2t,
+                                                const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
+                                                int64_t N, int64_t E, int32_t D, float negative_slope,
+                                                const float* out, int64_t ldo, const float* alpha,
+                                                const float* grad_out, int64_t ldg,
+                                                float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                                int32_t hub_threshold,
+                                                const int32_t* d_hub_rows, int64_t d_n_hubs, const int32_t* d_hub_seg_ptr,
+                                                const int32_t* d_seg_bounds, const int32_t* d_seg_node, int64_t d_n_segments,
+                                                const int32_t* s_hub_rows, int64_t s_n_hubs, const int32_t* s_hub_seg_ptr,
+                                                const int32_t* s_seg_bounds, const int32_t* s_seg_node, int64_t s_n_segments,
+                                                void* ws, size_t ws_bytes, void* stream);
+
 /* Pull-form backward for `heads` (2 or 3) interleaved narrow convs evaluated together (KT-GNN's classifier stage under
  * autograd: clf_base(x), clf_target(x), clf_target(T(x)), KTGNN.py:432-435, share the graph): tables / out / grad_out / dH are
  * [N][heads][4], a_* and da_* [heads][D] (da accumulated: caller zero-fills), D <= 4.  `state_ms` [N][heads][2] is the finished

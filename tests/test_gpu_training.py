@@ -331,3 +331,36 @@ def test_three_head_aggregation_backward_equals_three_single_heads(D, n, seed):
         assert _rel(tabs[h].grad.double(), tabs2[h].grad.double()) < 2e-5, f"table {h}"
         assert float(tabs[h].grad[:, D:].abs().max()) == 0.0 if D < 4 else True
     assert _rel(a_t.grad.double(), a_t2.grad.double()) < 1e-4 and _rel(a_s.grad.double(), a_s2.grad.double()) < 1e-4
+
+
+@pytest.mark.parametrize("D,seed", [(128, 0), (64, 1), (36, 2), (16, 3)])
+def test_pull_backward_with_hub_segments_equals_the_plain_pull(D, seed, monkeypatch):
+    """Graphs with hub rows (in-degree and out-degree >= ops.HUB_THRESHOLD): the segmented pull backward
+    (bgnn_adaptedconv_aggregate_bwd_pull_hub_f32) equals the plain one to fp32 rounding in every output, and is deterministic."""
+    from bridged_gnn_amd import ops, synth
+    n = 3000
+    ei, mask = synth.random_multigraph(n, 6 * n, frac_src=0.4, n_isolated=2, seed=seed)
+    rng = np.random.default_rng(seed)
+    hubs_in, hubs_out = rng.choice(n, size=5, replace=False), rng.choice(n, size=4, replace=False)
+    extra_in = np.stack([rng.integers(0, n, size=5 * 700), np.repeat(hubs_in, 700)])          # 700 in-edges each
+    extra_out = np.stack([np.repeat(hubs_out, 500), rng.integers(0, n, size=4 * 500)])         # 500 out-edges each
+    ei = np.concatenate([ei, extra_in, extra_out], axis=1).astype(np.int64)
+    csr = ops.build_dst_csr(_t(ei), n)
+    assert csr.hub_tables() is not None and csr.transposed_hub_tables() is not None
+    ld = ops.pad4(D)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    hS = torch.zeros(n, ld, device=DEV); hT = torch.zeros(n, ld, device=DEV)
+    hS[:, :D] = torch.randn(n, D, device=DEV, generator=g); hT[:, :D] = torch.randn(n, D, device=DEV, generator=g)
+    a1, a2 = torch.randn(D, device=DEV, generator=g) * 0.3, torch.randn(D, device=DEV, generator=g) * 0.3
+    m8 = _t(mask).to(torch.uint8)
+    monkeypatch.setenv("BGNN_HUB_ROWS", "0")
+    out, alpha = ops.adaptedconv_aggregate(hS, hT, a1, a2, csr, m8, D, 0.1, want_alpha=True)
+    gr = torch.zeros(n, ld, device=DEV); gr[:, :D] = torch.randn(n, D, device=DEV, generator=g)
+    plain = ops.adaptedconv_aggregate_bwd(hS, hT, a1, a2, csr, m8, D, out, alpha, gr, 0.1)
+    monkeypatch.delenv("BGNN_HUB_ROWS")
+    hub = ops.adaptedconv_aggregate_bwd(hS, hT, a1, a2, csr, m8, D, out, alpha, gr, 0.1)
+    hub2 = ops.adaptedconv_aggregate_bwd(hS, hT, a1, a2, csr, m8, D, out, alpha, gr, 0.1)
+    for name, a, b, c in zip(("dh_t2s", "dh_s2t", "da_t2s", "da_s2t"), hub, plain, hub2):
+        assert _rel(a.double().cpu(), b.double().cpu()) < (1e-5 if name.startswith("da") else 2e-6), name
+        if name.startswith("dh"):
+            assert torch.equal(a, c), name + " deterministic"
