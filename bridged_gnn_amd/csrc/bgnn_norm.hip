@@ -9,6 +9,9 @@
 namespace {
 
 constexpr int NT = 256;
+// the column sums are accumulated into NREP replicas (block b -> replica b % NREP) and added up by the readers: 2048 blocks x one
+// fp64 atomic per column on ONE address each retire at ~25 ns apiece -- 50 us of tail under a 10 MB input
+constexpr int NREP = 8;
 
 // dropout: 16 random bits per element, keep <=> bits >= thr (thr = round(p * 65536)); two 32-bit words per float4
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -48,19 +51,36 @@ __device__ __forceinline__ Lay lay_of(int D) {
   return l;
 }
 
-__device__ __forceinline__ void block_sum8_to_global(double v[8], const Lay& l, int D, double* out /*[2*D]*/) {
-  // rows of the block -> one value per column through LDS, then one fp64 atomic per (block, column, quantity)
+// accumulator layout (doubles): NREP x [2*D] replicas (block b adds into replica b % NREP); a reader block adds them up once,
+// cooperatively (block_totals).  (A "last block finalises" ticket on one address cost 2048 x 90 ns -- worse than what it saved.)
+__host__ __device__ inline size_t acc_doubles(int D) { return (size_t)NREP * 2 * D; }
+constexpr int MAXD = 1024;
+
+__device__ __forceinline__ void block_sum8_to_global(double v[8], const Lay& l, int D, double* out /*acc_doubles(D)*/) {
+  // rows of the block -> one value per column through LDS, then one fp64 atomic per (block, column, quantity) into the block's replica
   __shared__ double red[NT * 8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) red[c * NT + threadIdx.x] = l.on ? v[c] : 0.0;
   __syncthreads();
+  double* rep = out + (size_t)(blockIdx.x % NREP) * 2 * D;
   for (int t = threadIdx.x; t < 8 * l.lpr; t += NT) {
     const int c = t / l.lpr, cg = t % l.lpr;
     double s = 0.0;
     for (int r = 0; r < l.rpp; ++r) s += red[c * NT + r * l.lpr + cg];
     const int q = c >> 2, col = 4 * cg + (c & 3);
-    unsafeAtomicAdd(&out[q * D + col], s);
+    unsafeAtomicAdd(&rep[q * D + col], s);
   }
+}
+
+// totals of a replicated accumulator into LDS, by the whole block (one entry per thread and pass), then a barrier
+__device__ __forceinline__ void block_totals(const double* acc, int D, double* tot /*LDS [2*D]*/) {
+  for (int t = threadIdx.x; t < 2 * D; t += NT) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) s += acc[(size_t)r * 2 * D + t];
+    tot[t] = s;
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(NT) void colstats_kernel(NormParams p) {
@@ -78,12 +98,12 @@ __global__ __launch_bounds__(NT) void colstats_kernel(NormParams p) {
 }
 
 // batch mean / biased variance of this lane's 4 columns (fp64 from the sums), as fp32 mean and 1/sqrt(var + eps)
-__device__ __forceinline__ void col_consts(const NormParams& p, int cg, float mean[4], float rstd[4], float ga[4], float be[4]) {
+__device__ __forceinline__ void col_consts(const NormParams& p, const double* st /*totals [2*D]*/, int cg, float mean[4], float rstd[4], float ga[4], float be[4]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = 4 * cg + e;
-    const double m = p.stats[c] / (double)p.N;
-    double var = p.stats[p.D + c] / (double)p.N - m * m;
+    const double m = st[c] / (double)p.N;
+    double var = st[p.D + c] / (double)p.N - m * m;
     var = var > 0.0 ? var : 0.0;
     mean[e] = (float)m;
     rstd[e] = (float)(1.0 / sqrt(var + (double)p.eps));
@@ -94,10 +114,12 @@ __device__ __forceinline__ void col_consts(const NormParams& p, int cg, float me
 
 __global__ __launch_bounds__(NT) void bn_apply_kernel(NormParams p) {
   const Lay l = lay_of(p.D);
+  __shared__ double st[2 * MAXD];
+  block_totals(p.stats, p.D, st);
   if (blockIdx.x == 0 && p.running_mean != nullptr) {      // torch.nn.BatchNorm1d: unbiased variance into the running buffer
     for (int c = threadIdx.x; c < p.D; c += NT) {
-      const double m = p.stats[c] / (double)p.N;
-      double var = p.stats[p.D + c] / (double)p.N - m * m;
+      const double m = st[c] / (double)p.N;
+      double var = st[p.D + c] / (double)p.N - m * m;
       var = var > 0.0 ? var : 0.0;
       const double unb = p.N > 1 ? var * (double)p.N / (double)(p.N - 1) : var;
       p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)m;
@@ -106,7 +128,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(NormParams p) {
   }
   if (!l.on) return;
   float mean[4], rstd[4], ga[4], be[4];
-  col_consts(p, l.cg, mean, rstd, ga, be);
+  col_consts(p, st, l.cg, mean, rstd, ga, be);
   for (int64_t r = (int64_t)blockIdx.x * l.rpp + l.rof; r < p.N; r += (int64_t)gridDim.x * l.rpp) {
     const float4 a = *reinterpret_cast<const float4*>(p.x + r * p.ldx + 4 * l.cg);
     float o[4] = {a.x, a.y, a.z, a.w};
@@ -142,10 +164,12 @@ __device__ __forceinline__ void grad_prime(const NormParams& p, const Lay& l, in
 
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(NormParams p) {
   const Lay l = lay_of(p.D);
+  __shared__ double st[2 * MAXD];
+  block_totals(p.stats, p.D, st);
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (l.on) {
     float mean[4], rstd[4], ga[4], be[4];
-    col_consts(p, l.cg, mean, rstd, ga, be);
+    col_consts(p, st, l.cg, mean, rstd, ga, be);
     for (int64_t r = (int64_t)blockIdx.x * l.rpp + l.rof; r < p.N; r += (int64_t)gridDim.x * l.rpp) {
       float xh[4], gp[4];
       grad_prime(p, l, r, mean, rstd, ga, be, xh, gp);
@@ -161,13 +185,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(NormParams p) {
 
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(NormParams p) {
   const Lay l = lay_of(p.D);
+  __shared__ double st[2 * MAXD], gs[2 * MAXD];
+  block_totals(p.stats, p.D, st);
+  block_totals(p.gsum, p.D, gs);
   if (!l.on) return;
   float mean[4], rstd[4], ga[4], be[4], c1[4], c2[4];
-  col_consts(p, l.cg, mean, rstd, ga, be);
+  col_consts(p, st, l.cg, mean, rstd, ga, be);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    c1[e] = (float)(p.gsum[4 * l.cg + e] / (double)p.N);
-    c2[e] = (float)(p.gsum[p.D + 4 * l.cg + e] / (double)p.N);
+    c1[e] = (float)(gs[4 * l.cg + e] / (double)p.N);
+    c2[e] = (float)(gs[p.D + 4 * l.cg + e] / (double)p.N);
   }
   for (int64_t r = (int64_t)blockIdx.x * l.rpp + l.rof; r < p.N; r += (int64_t)gridDim.x * l.rpp) {
     float xh[4], gp[4], o[4];
@@ -198,6 +225,8 @@ void drop_consts(float p_drop, uint32_t& thr, float& scale) {
 
 }  // namespace
 
+extern "C" int64_t bgnn_bn_acc_doubles(int32_t D) { return (int64_t)acc_doubles(D > 0 ? D : 0); }
+
 extern "C" int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, int64_t ldx, const float* gamma_opt,
                                         const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed,
                                         float momentum, float* running_mean_opt, float* running_var_opt,
@@ -207,7 +236,7 @@ extern "C" int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, in
   if (!shape_ok(N, D, ldx) || !shape_ok(N, D, ldy) || !(p_drop >= 0.f && p_drop < 1.f)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(y)) return BGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (hipMemsetAsync(stats, 0, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (N == 0) return 0;
   NormParams p{};
   p.x = x; p.N = N; p.D = D; p.ldx = ldx; p.stats = stats; p.gamma = gamma_opt; p.beta = beta_opt; p.eps = eps;
@@ -230,7 +259,7 @@ extern "C" int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y,
   if (!shape_ok(N, D, ldx) || !shape_ok(N, D, ldg) || !shape_ok(N, D, ldgx) || !(p_drop >= 0.f && p_drop < 1.f)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(grad_y) || !bgnn_aligned16(grad_x)) return BGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(gsum, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (hipMemsetAsync(gsum, 0, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (N == 0) return 0;
   NormParams p{};
   p.x = x; p.N = N; p.D = D; p.ldx = ldx; p.stats = stats; p.gamma = gamma_opt; p.beta = beta_opt; p.eps = eps;

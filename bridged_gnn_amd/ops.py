@@ -299,7 +299,7 @@ def bn_relu_dropout(x, gamma, beta, eps, relu, p_drop, seed, momentum=0.0, runni
     is what the backward needs besides x."""
     N, D = x.shape
     y = torch.empty(N, D, dtype=torch.float32, device=x.device)
-    stats = torch.empty(2 * D, dtype=torch.float64, device=x.device)
+    stats = torch.empty(L.lib().bgnn_bn_acc_doubles(D), dtype=torch.float64, device=x.device)   # R x [2D] partial accumulators
     rc = L.lib().bgnn_bn_relu_dropout_f32(L.ptr_rows(x), N, D, x.stride(0), L.ptr(gamma) if gamma is not None else None,
                                           L.ptr(beta) if beta is not None else None, float(eps), int(bool(relu)), float(p_drop),
                                           int(seed) & 0xFFFFFFFFFFFFFFFF, float(momentum),
@@ -314,13 +314,13 @@ def bn_relu_dropout_bwd(x, grad_y, stats, gamma, beta, eps, relu, p_drop, seed):
     """-> (dL/dx [N,D], gsum fp64 [2*D] = dL/dbeta | dL/dgamma)."""
     N, D = x.shape
     gx = torch.empty(N, D, dtype=torch.float32, device=x.device)
-    gsum = torch.empty(2 * D, dtype=torch.float64, device=x.device)
+    gsum = torch.empty(L.lib().bgnn_bn_acc_doubles(D), dtype=torch.float64, device=x.device)
     rc = L.lib().bgnn_bn_relu_dropout_bwd_f32(L.ptr_rows(x), L.ptr_rows(grad_y), N, D, x.stride(0), grad_y.stride(0), L.ptr(stats),
                                               L.ptr(gamma) if gamma is not None else None, L.ptr(beta) if beta is not None else None,
                                               float(eps), int(bool(relu)), float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                               L.ptr(gx), D, L.ptr(gsum), L.stream())
     L.check(rc, "bgnn_bn_relu_dropout_bwd_f32")
-    return gx, gsum
+    return gx, gsum.view(-1, 2 * D).sum(0)
 
 
 def rowdot(X, V):

@@ -119,13 +119,14 @@ int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float* B, int64_
                   float* out /*[p][q]*/, void* ws, size_t ws_bytes, void* stream);
 /* Training-mode BatchNorm1d -> ReLU -> dropout over node rows (models/KTGNN.py:420-430: `self.bns[ind](x)`, `F.relu`,
  *   `F.dropout(x, p=self.dropout, training=self.training)`; :364-367 clf_transformer's BatchNorm1d + ReLU with p = 0) in two
- *   streaming launches.  x [N, D] (D % 4 == 0, D <= 1024), batch statistics over the N rows in fp64 (`stats` [2*D]: column sums
+ *   streaming launches.  x [N, D] (D % 4 == 0, D <= 1024), batch statistics over the N rows in fp64 (`stats`, bgnn_bn_acc_doubles(D) doubles = R x [2*D] partials: column sums
  *   of x | x^2, written here and kept for the backward); y = keep(seed, element) ? max(gamma*(x-mean)/sqrt(var+eps)+beta, 0) / (1-p) : 0.
  *   The dropout mask is a counter-based hash of (seed, element index) with 16 bits per element (p is rounded to 1/65536) -- the
  *   same Bernoulli(1-p) law as torch's Philox stream, not the same bits.  running_mean / running_var (both or neither) get torch's
  *   momentum update with the unbiased variance.
  * bgnn_bn_relu_dropout_bwd_f32: dL/dx from dL/dy; the ReLU state is re-derived from x and the mask from (seed, index); `gsum`
- *   [2*D] (fp64, written here) returns sum g' = dL/dbeta and sum g'.xhat = dL/dgamma (g' = dL/d(BN output)). */
+ *   (bgnn_bn_acc_doubles(D) doubles = R x [2*D] partials, written here; summed over R) returns sum g' = dL/dbeta and sum g'.xhat = dL/dgamma (g' = dL/d(BN output)). */
+int64_t bgnn_bn_acc_doubles(int32_t D);   /* size in doubles of `stats` / `gsum` below: R partial accumulators of [2*D]; their sum over R is the total */
 int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, int64_t ldx, const float* gamma_opt,
                              const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed,
                              float momentum, float* running_mean_opt, float* running_var_opt,
