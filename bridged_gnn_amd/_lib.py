@@ -58,6 +58,10 @@ SIGNATURES = {
     "bgnn_aggregate_heads_bwd_workspace_bytes": (C.c_size_t, [_I64, _I64, _I32]),
     "bgnn_adaptedconv_aggregate_heads_bwd_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F32,
                                                          _P, _P, _P, _INT, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "bgnn_aggregate_heads_bwd_hub_workspace_bytes": (C.c_size_t, [_I64, _I64, _I32, _I64, _I64]),
+    "bgnn_adaptedconv_aggregate_heads_bwd_hub_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F32,
+                                                             _P, _P, _P, _INT, _P, _P, _P, _P, _I32,
+                                                             _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, C.c_size_t, _P]),
     "bgnn_l2_normalize_rows_f32": (_INT, [_P, _I64, _I32, _F32, _P, _P]),
     "bgnn_topk_workspace_bytes": (_SZ, [_I64, _I64, _I32]),
     "bgnn_cosine_topk_f32": (_INT, [_P, _P, _I64, _I64, _I32, _I32, _INT, _P, _P, _P, _P, _SZ, _P]),

@@ -533,6 +533,10 @@ struct HeadsBwdParams {
   float4* node;          // [N][3 * HEADS]: h_i[HEADS] | gr_i[HEADS] | per head (m, 1/s, t_i, domain)
   float* dstside;        // [N][HEADS][4]
   float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
+  // hub rows: as in PullParams (segments behind the real rows of each pass, partial rows of HEADS * 4 floats, fixed-order merges)
+  int32_t hub_threshold;
+  const int32_t* d_vnode; const int32_t* d_vbounds; int64_t d_nv; float* d_vpart;
+  const int32_t* s_vnode; const int32_t* s_vbounds; int64_t s_nv; float* s_vpartS; float* s_vpartT;
 };
 
 __device__ __forceinline__ float4 mask_cols(float4 v, int D) {
@@ -568,18 +572,26 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p
   const bool lane_on = g < GPW;
   constexpr int64_t rs = HEADS * 4;
   float4 accS = make_float4(0.f, 0.f, 0.f, 0.f), accT = accS;
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  const int64_t ntiles = (p.N + p.d_nv + RPB - 1) / RPB;     // real rows, then the hub destinations' segments
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
   for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
     const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
     if (tile < 0) continue;
-    const int64_t i = tile * RPB + wave * GPW + g;
-    const bool rvalid = lane_on && i < p.N;
+    const int64_t i0 = tile * RPB + wave * GPW + g;
+    const bool in_range = lane_on && i0 < p.N + p.d_nv;
+    const bool virt = in_range && i0 >= p.N;                    // a segment of a hub destination
+    const int64_t vix = virt ? i0 - p.N : 0;
+    const int64_t i = virt ? (int64_t)p.d_vnode[vix] : i0;
+    const bool rvalid = in_range;
     const int64_t ic = rvalid ? i : 0;
     const bool dom_s = p.mask[ic] != 0;
     const float* __restrict__ H = dom_s ? p.h_t2s : p.h_s2t;
     const float* __restrict__ av = dom_s ? p.a_t2s : p.a_s2t;
-    const int32_t beg = rvalid ? p.rowptr[ic] : 0, end = rvalid ? p.rowptr[ic + 1] : 0;
+    int32_t beg = rvalid ? (virt ? p.d_vbounds[2 * vix] : p.rowptr[ic]) : 0;
+    int32_t end = rvalid ? (virt ? p.d_vbounds[2 * vix + 1] : p.rowptr[ic + 1]) : 0;
+    // a hub row still leaves its node record here (pass B reads it); its edges and its dstside row belong to the segments
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;
+    if (hub) { beg = 0; end = 0; }
     float4 a4;
     a4.x = av[h * p.D];
     a4.y = p.D > 1 ? av[h * p.D + 1] : 0.f;
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p
     const float ti = gi.x * oi.x + gi.y * oi.y + gi.z * oi.z + gi.w * oi.w;
     const float mh = p.state_ms[2 * (ic * HEADS + h)];
     const float inv = 1.f / (p.state_ms[2 * (ic * HEADS + h) + 1] + 1e-16f);
-    if (rvalid && sub == 0) {
+    if (rvalid && !virt && sub == 0) {
       float4* nd = p.node + i * (3 * HEADS);
       nd[h] = hi;
       nd[HEADS + h] = gi;
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_dst_kernel(HeadsBwdParams p
       accd.x += __shfl(accd.x, from); accd.y += __shfl(accd.y, from);
       accd.z += __shfl(accd.z, from); accd.w += __shfl(accd.w, from);
     }
-    if (rvalid && sub == 0) *reinterpret_cast<float4*>(p.dstside + i * rs + 4 * h) = accd;
+    if (rvalid && !hub && sub == 0) *reinterpret_cast<float4*>((virt ? p.d_vpart + vix * rs : p.dstside + i * rs) + 4 * h) = accd;
     if (rvalid) {
       if (dom_s) { accS.x += accz.x; accS.y += accz.y; accS.z += accz.z; accS.w += accz.w; }
       else       { accT.x += accz.x; accT.y += accz.y; accT.z += accz.z; accT.w += accz.w; }
@@ -664,15 +676,22 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
   aS.z = p.D > 2 ? p.a_t2s[h * p.D + 2] : 0.f; aS.w = p.D > 3 ? p.a_t2s[h * p.D + 3] : 0.f;
   aT.x = p.a_s2t[h * p.D]; aT.y = p.D > 1 ? p.a_s2t[h * p.D + 1] : 0.f;
   aT.z = p.D > 2 ? p.a_s2t[h * p.D + 2] : 0.f; aT.w = p.D > 3 ? p.a_s2t[h * p.D + 3] : 0.f;
-  const int64_t ntiles = (p.N + RPB - 1) / RPB;
+  const int64_t ntiles = (p.N + p.s_nv + RPB - 1) / RPB;     // real rows, then the hub sources' segments
   bgnn::XcdRange tr = bgnn::xcd_pos_range(ntiles);
   for (int64_t pos = tr.begin; pos < tr.end; pos += tr.step) {
     const int64_t tile = bgnn::xcd_tile_of(pos, ntiles);
     if (tile < 0) continue;
-    const int64_t j = tile * RPB + wave * GPW + g;
-    const bool rvalid = lane_on && j < p.N;
-    const int64_t jc = rvalid ? j : 0;
-    const int32_t beg = rvalid ? p.t_rowptr[jc] : 0, end = rvalid ? p.t_rowptr[jc + 1] : 0;
+    const int64_t j0 = tile * RPB + wave * GPW + g;
+    const bool in_range = lane_on && j0 < p.N + p.s_nv;
+    const bool virt = in_range && j0 >= p.N;                    // a segment of a hub source
+    const int64_t vix = virt ? j0 - p.N : 0;
+    const int64_t j = virt ? (int64_t)p.s_vnode[vix] : j0;
+    const int64_t jc = in_range ? j : 0;
+    int32_t beg = in_range ? (virt ? p.s_vbounds[2 * vix] : p.t_rowptr[jc]) : 0;
+    int32_t end = in_range ? (virt ? p.s_vbounds[2 * vix + 1] : p.t_rowptr[jc + 1]) : 0;
+    const bool hub = !virt && p.hub_threshold > 0 && end - beg >= p.hub_threshold;
+    const bool rvalid = in_range && !hub;
+    if (hub) { beg = 0; end = 0; }
     // row j of both tables: the destination's domain picks one
     const float4 hS = *reinterpret_cast<const float4*>(p.h_t2s + jc * rs + 4 * h);
     const float4 hT = *reinterpret_cast<const float4*>(p.h_s2t + jc * rs + 4 * h);
@@ -707,7 +726,10 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
       accS.x += __shfl(accS.x, from); accS.y += __shfl(accS.y, from); accS.z += __shfl(accS.z, from); accS.w += __shfl(accS.w, from);
       accT.x += __shfl(accT.x, from); accT.y += __shfl(accT.y, from); accT.z += __shfl(accT.z, from); accT.w += __shfl(accT.w, from);
     }
-    if (rvalid && sub == 0) {
+    if (virt && sub == 0) {                                      // a segment: its partial sums, merged afterwards
+      *reinterpret_cast<float4*>(p.s_vpartS + vix * rs + 4 * h) = accS;
+      *reinterpret_cast<float4*>(p.s_vpartT + vix * rs + 4 * h) = accT;
+    } else if (rvalid && sub == 0) {
       const float4 ds4 = *reinterpret_cast<const float4*>(p.dstside + j * rs + 4 * h);
       if (dom_j) { accS.x += ds4.x; accS.y += ds4.y; accS.z += ds4.z; accS.w += ds4.w; }
       else       { accT.x += ds4.x; accT.y += ds4.y; accT.z += ds4.z; accT.w += ds4.w; }
@@ -715,26 +737,6 @@ __global__ __launch_bounds__(256) void agg_heads_bwd_src_kernel(HeadsBwdParams p
       *reinterpret_cast<float4*>(p.dh_s2t + j * rs + 4 * h) = accT;
     }
   }
-}
-
-template <int HEADS>
-int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st) {
-  // (EP, U) = (2, 4) from a sweep on C4, both passes together: lane per head 2/4 0.69, 1/4 0.70, 1/2 0.73, 2/2 0.74, 4/4 0.74,
-  // 4/2 0.80 ms (one lane for all heads: 1.33 ms); tools/heads_bwd_time.py times this pair of launches
-#define BGNN_HB(EPV, UV)                                                                                               \
-  do {                                                                                                                 \
-    constexpr int RPB = 4 * (64 / (EPV * HEADS));                                                                      \
-    const int64_t ntiles = (p.N + RPB - 1) / RPB;                                                                      \
-    int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;                                                        \
-    if (grid < 8) grid = 8;                                                                                            \
-    hipLaunchKernelGGL((agg_heads_bwd_dst_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
-    BGNN_LAUNCH_CHECK();                                                                                               \
-    hipLaunchKernelGGL((agg_heads_bwd_src_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);         \
-    BGNN_LAUNCH_CHECK();                                                                                               \
-    return 0;                                                                                                          \
-  } while (0)
-  BGNN_HB(2, 4);
-#undef BGNN_HB
 }
 
 // merges of the hub segments' partial rows (fixed order).  One thread per float4 of a hub row.
@@ -776,6 +778,33 @@ struct PullHubs {        // host side of the hub tables (device pointers)
   const int32_t* d_rows; const int32_t* d_seg_ptr; int64_t d_nh;
   const int32_t* s_rows; const int32_t* s_seg_ptr; int64_t s_nh;
 };
+
+template <int HEADS>
+int launch_heads_bwd(const HeadsBwdParams& p, hipStream_t st, const PullHubs* hubs = nullptr) {
+  // (EP, U) = (2, 4) from a sweep on C4, both passes together: lane per head 2/4 0.69, 1/4 0.70, 1/2 0.73, 2/2 0.74, 4/4 0.74,
+  // 4/2 0.80 ms (one lane for all heads: 1.33 ms); tools/heads_bwd_time.py times this pair of launches
+  constexpr int EPV = 2, UV = 4, RPB = 4 * (64 / (EPV * HEADS));
+  const int64_t nmax = p.N + (p.d_nv > p.s_nv ? p.d_nv : p.s_nv);
+  const int64_t ntiles = (nmax + RPB - 1) / RPB;
+  int64_t grid = ntiles < 2048 ? (ntiles + 7) / 8 * 8 : 2048;
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL((agg_heads_bwd_dst_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  const int64_t ld = HEADS * 4;
+  if (hubs && hubs->d_nh > 0) {            // the hub destinations' dstside rows, before pass B reads them
+    PullMergeParams m{hubs->d_rows, hubs->d_seg_ptr, hubs->d_nh, ld, p.d_vpart, nullptr, p.mask, p.dstside, nullptr, nullptr};
+    hipLaunchKernelGGL(pull_merge_dst_kernel, dim3((unsigned)((hubs->d_nh * (ld / 4) + 255) / 256)), dim3(256), 0, st, m);
+    BGNN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((agg_heads_bwd_src_kernel<HEADS, EPV, UV>), dim3((unsigned)grid), dim3(256), 0, st, p);
+  BGNN_LAUNCH_CHECK();
+  if (hubs && hubs->s_nh > 0) {
+    PullMergeParams m{hubs->s_rows, hubs->s_seg_ptr, hubs->s_nh, ld, p.s_vpartS, p.s_vpartT, p.mask, p.dstside, p.dh_t2s, p.dh_s2t};
+    hipLaunchKernelGGL(pull_merge_src_kernel, dim3((unsigned)((hubs->s_nh * (ld / 4) + 255) / 256)), dim3(256), 0, st, m);
+    BGNN_LAUNCH_CHECK();
+  }
+  return 0;
+}
 
 template <int LF>
 int launch_pull(const PullParams& p, hipStream_t st, const PullHubs* hubs = nullptr) {
@@ -935,6 +964,39 @@ extern "C" size_t bgnn_aggregate_heads_bwd_workspace_bytes(int64_t N, int64_t E,
   return bgnn_align_up(sizeof(float4) * n * 3 * h, 256) + bgnn_align_up(sizeof(float) * n * h * 4, 256) + 256;
 }
 
+static int heads_bwd_impl(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
+                          const int32_t* rowptr, const int32_t* col, const uint8_t* mask, const int32_t* t_rowptr, const int32_t* t_dst,
+                          int64_t N, int64_t E, int32_t D, int32_t heads, float negative_slope, const float* out, const float* state_ms,
+                          const float* grad_out, int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                          int32_t hub_threshold, const PullHubs* hubs, const int32_t* d_vbounds, const int32_t* d_vnode, int64_t d_nv,
+                          const int32_t* s_vbounds, const int32_t* s_vnode, int64_t s_nv, void* ws, size_t ws_bytes, void* stream) {
+  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_dst || !out || !state_ms ||
+      !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
+    return BGNN_E_NULL;
+  if (N < 0 || E < 0 || D < 1 || D > 4 || (heads != 2 && heads != 3)) return BGNN_E_SHAPE;
+  if (hubs && (hub_threshold < 2 || d_nv < 0 || s_nv < 0)) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
+      !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
+    return BGNN_E_ALIGN;
+  const size_t base_bytes = bgnn_aggregate_heads_bwd_workspace_bytes(N, E, heads);
+  const size_t seg_bytes = hubs ? bgnn_align_up(sizeof(float) * (size_t)heads * 4 * (size_t)(d_nv + 2 * s_nv), 256) + 256 : 0;
+  if (ws_bytes < base_bytes + seg_bytes) return BGNN_E_WORKSPACE;
+  if (N == 0) return 0;
+  float4* node = (float4*)ws;
+  float* dstside = (float*)((char*)ws + bgnn_align_up(sizeof(float4) * (size_t)N * 3 * (size_t)heads, 256));
+  HeadsBwdParams p{h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, state_ms, grad_out, log_softmax,
+                   t_rowptr, t_dst, node, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
+  if (hubs) {
+    float* seg = (float*)((char*)ws + bgnn_align_up(base_bytes, 256));
+    const size_t ld = (size_t)heads * 4;
+    p.hub_threshold = hub_threshold;
+    p.d_vnode = d_vnode; p.d_vbounds = d_vbounds; p.d_nv = d_nv; p.d_vpart = seg;
+    p.s_vnode = s_vnode; p.s_vbounds = s_vbounds; p.s_nv = s_nv; p.s_vpartS = seg + (size_t)d_nv * ld; p.s_vpartT = seg + (size_t)(d_nv + s_nv) * ld;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return heads == 3 ? launch_heads_bwd<3>(p, st, hubs) : launch_heads_bwd<2>(p, st, hubs);
+}
+
 extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
                                                         const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
                                                         const int32_t* t_rowptr, const int32_t* t_eid, const int32_t* t_dst,
@@ -943,19 +1005,36 @@ extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, cons
                                                         int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s,
                                                         float* da_s2t, void* ws, size_t ws_bytes, void* stream) {
   (void)t_eid;                                   // (kept in the signature: the by-source view is passed as one triple everywhere)
-  if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !t_rowptr || !t_dst || !out || !state_ms ||
-      !grad_out || !dh_t2s || !dh_s2t || !da_t2s || !da_s2t || !ws)
+  return heads_bwd_impl(h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, t_rowptr, t_dst, N, E, D, heads, negative_slope, out, state_ms,
+                        grad_out, log_softmax, dh_t2s, dh_s2t, da_t2s, da_s2t, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                        ws, ws_bytes, stream);
+}
+
+extern "C" size_t bgnn_aggregate_heads_bwd_hub_workspace_bytes(int64_t N, int64_t E, int32_t heads, int64_t d_segments, int64_t s_segments) {
+  const size_t nseg = (size_t)(d_segments > 0 ? d_segments : 0) + 2 * (size_t)(s_segments > 0 ? s_segments : 0);
+  return bgnn_align_up(bgnn_aggregate_heads_bwd_workspace_bytes(N, E, heads), 256) +
+         bgnn_align_up(sizeof(float) * (size_t)(heads > 0 ? heads : 0) * 4 * nseg, 256) + 512;
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_heads_bwd_hub_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
+                                                            const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                            const int32_t* t_rowptr, const int32_t* t_dst,
+                                                            int64_t N, int64_t E, int32_t D, int32_t heads, float negative_slope,
+                                                            const float* out, const float* state_ms, const float* grad_out,
+                                                            int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                                            int32_t hub_threshold,
+                                                            const int32_t* d_hub_rows, int64_t d_n_hubs, const int32_t* d_hub_seg_ptr,
+                                                            const int32_t* d_seg_bounds, const int32_t* d_seg_node, int64_t d_n_segments,
+                                                            const int32_t* s_hub_rows, int64_t s_n_hubs, const int32_t* s_hub_seg_ptr,
+                                                            const int32_t* s_seg_bounds, const int32_t* s_seg_node, int64_t s_n_segments,
+                                                            void* ws, size_t ws_bytes, void* stream) {
+  if (d_n_hubs < 0 || s_n_hubs < 0 || d_n_segments < d_n_hubs || s_n_segments < s_n_hubs) return BGNN_E_SHAPE;
+  if ((d_n_hubs > 0 && (!d_hub_rows || !d_hub_seg_ptr || !d_seg_bounds || !d_seg_node)) ||
+      (s_n_hubs > 0 && (!s_hub_rows || !s_hub_seg_ptr || !s_seg_bounds || !s_seg_node)))
     return BGNN_E_NULL;
-  if (N < 0 || E < 0 || D < 1 || D > 4 || (heads != 2 && heads != 3)) return BGNN_E_SHAPE;
-  if (!bgnn_aligned16(h_t2s) || !bgnn_aligned16(h_s2t) || !bgnn_aligned16(out) || !bgnn_aligned16(grad_out) ||
-      !bgnn_aligned16(dh_t2s) || !bgnn_aligned16(dh_s2t) || !bgnn_aligned16(ws))
-    return BGNN_E_ALIGN;
-  if (ws_bytes < bgnn_aggregate_heads_bwd_workspace_bytes(N, E, heads)) return BGNN_E_WORKSPACE;
-  if (N == 0) return 0;
-  float4* node = (float4*)ws;
-  float* dstside = (float*)((char*)ws + bgnn_align_up(sizeof(float4) * (size_t)N * 3 * (size_t)heads, 256));
-  HeadsBwdParams p{h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, N, D, negative_slope, out, state_ms, grad_out, log_softmax,
-                   t_rowptr, t_dst, node, dstside, dh_t2s, dh_s2t, da_t2s, da_s2t};
-  hipStream_t st = (hipStream_t)stream;
-  return heads == 3 ? launch_heads_bwd<3>(p, st) : launch_heads_bwd<2>(p, st);
+  PullHubs hubs{d_hub_rows, d_hub_seg_ptr, d_n_hubs, s_hub_rows, s_hub_seg_ptr, s_n_hubs};
+  return heads_bwd_impl(h_t2s, h_s2t, a_t2s, a_s2t, rowptr, col, mask, t_rowptr, t_dst, N, E, D, heads, negative_slope, out, state_ms,
+                        grad_out, log_softmax, dh_t2s, dh_s2t, da_t2s, da_s2t, hub_threshold, &hubs,
+                        d_seg_bounds, d_seg_node, d_n_hubs > 0 ? d_n_segments : 0, s_seg_bounds, s_seg_node, s_n_hubs > 0 ? s_n_segments : 0,
+                        ws, ws_bytes, stream);
 }

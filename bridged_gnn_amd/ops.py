@@ -542,6 +542,25 @@ def adaptedconv_aggregate_heads_bwd(t2s, s2t, a_t2s, a_s2t, csr, mask_u8, D, hea
     da_s2t = torch.zeros(heads, D, dtype=torch.float32, device=dev)
     dh_t2s, dh_s2t = torch.empty_like(t2s), torch.empty_like(s2t)
     t_rowptr, t_eid, t_dst = csr.transposed()
+    dh_, sh_ = (csr.hub_tables(), csr.transposed_hub_tables()) if os.environ.get("BGNN_HUB_ROWS", "1") != "0" else (None, None)
+    if dh_ is not None or sh_ is not None:          # graphs with hub rows: segments + merges (bgnn.h)
+        none4 = (None, None, None, None)
+        d_rows, d_ptr, d_bounds, d_node = dh_ if dh_ is not None else none4
+        s_rows, s_ptr, s_bounds, s_node = sh_ if sh_ is not None else none4
+        nd = 0 if dh_ is None else int(d_node.numel())
+        ns = 0 if sh_ is None else int(s_node.numel())
+        wsb = lib.bgnn_aggregate_heads_bwd_hub_workspace_bytes(N, csr.num_edges, heads, nd, ns)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.bgnn_adaptedconv_aggregate_heads_bwd_hub_f32(
+            L.ptr(t2s), L.ptr(s2t), L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(mask_u8),
+            L.ptr(t_rowptr), L.ptr(t_dst), N, csr.num_edges, D, heads, float(negative_slope),
+            L.ptr(out), L.ptr(state_ms), L.ptr(grad_out), int(bool(log_softmax)), L.ptr(dh_t2s), L.ptr(dh_s2t),
+            L.ptr(da_t2s), L.ptr(da_s2t), HUB_THRESHOLD,
+            L.ptr(d_rows), 0 if dh_ is None else int(d_rows.numel()), L.ptr(d_ptr), L.ptr(d_bounds), L.ptr(d_node), nd,
+            L.ptr(s_rows), 0 if sh_ is None else int(s_rows.numel()), L.ptr(s_ptr), L.ptr(s_bounds), L.ptr(s_node), ns,
+            L.ptr(ws), wsb, L.stream())
+        L.check(rc, "bgnn_adaptedconv_aggregate_heads_bwd_hub_f32")
+        return dh_t2s, dh_s2t, da_t2s, da_s2t
     wsb = lib.bgnn_aggregate_heads_bwd_workspace_bytes(N, csr.num_edges, heads)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     rc = lib.bgnn_adaptedconv_aggregate_heads_bwd_f32(

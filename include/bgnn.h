@@ -314,6 +314,20 @@ int bgnn_adaptedconv_aggregate_heads_bwd_f32(const float* h_t2s, const float* h_
                                              const float* out, const float* state_ms, const float* grad_out,
                                              int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s,
                                              float* da_s2t, void* ws, size_t ws_bytes, void* stream);
+/* ... and for graphs with hub rows (tables as in bgnn_adaptedconv_aggregate_bwd_pull_hub_f32; partial rows of heads * 4 floats). */
+size_t bgnn_aggregate_heads_bwd_hub_workspace_bytes(int64_t N, int64_t E, int32_t heads, int64_t d_segments, int64_t s_segments);
+int bgnn_adaptedconv_aggregate_heads_bwd_hub_f32(const float* h_t2s, const float* h_s2t, const float* a_t2s, const float* a_s2t,
+                                                 const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                 const int32_t* t_rowptr, const int32_t* t_dst,
+                                                 int64_t N, int64_t E, int32_t D, int32_t heads, float negative_slope,
+                                                 const float* out, const float* state_ms, const float* grad_out,
+                                                 int log_softmax, float* dh_t2s, float* dh_s2t, float* da_t2s, float* da_s2t,
+                                                 int32_t hub_threshold,
+                                                 const int32_t* d_hub_rows, int64_t d_n_hubs, const int32_t* d_hub_seg_ptr,
+                                                 const int32_t* d_seg_bounds, const int32_t* d_seg_node, int64_t d_n_segments,
+                                                 const int32_t* s_hub_rows, int64_t s_n_hubs, const int32_t* s_hub_seg_ptr,
+                                                 const int32_t* s_seg_bounds, const int32_t* s_seg_node, int64_t s_n_segments,
+                                                 void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a2,a3,a5,a6,a7) kNN bridge: pair scoring + per-query top-k.

@@ -364,3 +364,38 @@ def test_pull_backward_with_hub_segments_equals_the_plain_pull(D, seed, monkeypa
         assert _rel(a.double().cpu(), b.double().cpu()) < (1e-5 if name.startswith("da") else 2e-6), name
         if name.startswith("dh"):
             assert torch.equal(a, c), name + " deterministic"
+
+
+@pytest.mark.parametrize("D,heads,seed", [(2, 3, 0), (4, 2, 1), (3, 3, 2)])
+def test_heads_backward_with_hub_segments_equals_the_plain_one(D, heads, seed, monkeypatch):
+    """the interleaved-heads pull backward on a graph with in- and out-degree hubs: segments + fixed-order merges
+    (bgnn_adaptedconv_aggregate_heads_bwd_hub_f32) == the plain kernels (fp32 rounding), deterministic."""
+    from bridged_gnn_amd import ops, synth
+    n = 3000
+    ei, mask = synth.random_multigraph(n, 6 * n, frac_src=0.4, n_isolated=2, seed=seed)
+    rng = np.random.default_rng(seed)
+    hubs_in, hubs_out = rng.choice(n, size=5, replace=False), rng.choice(n, size=4, replace=False)
+    ei = np.concatenate([ei, np.stack([rng.integers(0, n, size=5 * 700), np.repeat(hubs_in, 700)]),
+                         np.stack([np.repeat(hubs_out, 500), rng.integers(0, n, size=4 * 500)])], axis=1).astype(np.int64)
+    csr = ops.build_dst_csr(_t(ei), n)
+    assert csr.hub_tables() is not None and csr.transposed_hub_tables() is not None
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    m8 = _t(mask).to(torch.uint8)
+    t2s = torch.zeros(n, heads * 4, device=DEV); s2t = torch.zeros(n, heads * 4, device=DEV)
+    for h in range(heads):
+        t2s[:, 4 * h:4 * h + D] = torch.randn(n, D, device=DEV, generator=g)
+        s2t[:, 4 * h:4 * h + D] = torch.randn(n, D, device=DEV, generator=g)
+    a1 = torch.randn(heads, D, device=DEV, generator=g) * 0.3; a2 = torch.randn(heads, D, device=DEV, generator=g) * 0.3
+    ms = torch.zeros(n, heads, 2, device=DEV)
+    out = ops.adaptedconv_aggregate(t2s, s2t, a1, a2, csr, m8, D, 0.1, heads=heads, log_softmax=True, state_ms=ms, part=3)
+    gr = torch.zeros(n, heads * 4, device=DEV)
+    for h in range(heads):
+        gr[:, 4 * h:4 * h + D] = torch.randn(n, D, device=DEV, generator=g)
+    hub = ops.adaptedconv_aggregate_heads_bwd(t2s, s2t, a1, a2, csr, m8, D, heads, out, ms, gr, True, 0.1)
+    hub2 = ops.adaptedconv_aggregate_heads_bwd(t2s, s2t, a1, a2, csr, m8, D, heads, out, ms, gr, True, 0.1)
+    monkeypatch.setenv("BGNN_HUB_ROWS", "0")
+    plain = ops.adaptedconv_aggregate_heads_bwd(t2s, s2t, a1, a2, csr, m8, D, heads, out, ms, gr, True, 0.1)
+    for name, a, b, c in zip(("dh_t2s", "dh_s2t", "da_t2s", "da_s2t"), hub, plain, hub2):
+        assert _rel(a.double().cpu(), b.double().cpu()) < (1e-5 if name.startswith("da") else 2e-6), name
+        if name.startswith("dh"):
+            assert torch.equal(a, c), name + " deterministic"
