@@ -45,7 +45,7 @@ SIGNATURES = {
                                                _P, _I64, _P, _P, _P, _INT, _P, _INT, _I64, _I32, _P, _P, _P]),
     "bgnn_aggregate_hub_workspace_bytes": (C.c_size_t, [_I64, _I32, _I64]),
     "bgnn_adaptedconv_aggregate_hub_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _F32, _P, _I64, _P, _P, _INT, _P, _I32, _P,
-                                                   _P, _I32, _P, _I64, _P, _P, _P, _I64, _P, C.c_size_t, _P]),
+                                                   _P, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, C.c_size_t, _P]),
     "bgnn_adaptedconv_aggregate_bwd_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
                                                    _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "bgnn_aggregate_bwd_pull_workspace_bytes": (C.c_size_t, [_I64, _I64, _I64]),

@@ -807,6 +807,7 @@ struct HubMergeParams {
   int32_t D; int64_t ldo; int32_t heads;
   float* out; const float* ep_scale; const float* ep_shift; int ep_relu;
   double* colsum; float* state_ms;
+  float* alpha; const int32_t* rowptr;   // training forward: the segments left RAW logits in alpha[e]; normalised here with the row's (m, s)
 };
 
 // wide rows (heads == 1): LF lanes own a hub row, one float4 of columns each
@@ -853,6 +854,10 @@ __global__ __launch_bounds__(256) void hub_merge_wide_kernel(HubMergeParams p) {
         acc.z = acc.z * c1 + b[u].z * c2; acc.w = acc.w * c1 + b[u].w * c2;
         m = mn;
       }
+    }
+    if (p.alpha != nullptr) {                // the same expression as the aggregation kernel's own normalisation
+      const float inv = 1.f / (s + 1e-16f);
+      for (int32_t e = p.rowptr[node] + lane; e < p.rowptr[node + 1]; e += LF) p.alpha[e] = __expf(p.alpha[e] - m) * inv;
     }
     if (f0 < p.ldo) {
       const float inv = 1.f / (s + 1e-16f);
@@ -1006,9 +1011,10 @@ extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const floa
                                                   float* state_ms_opt, int32_t heads, double* colsum_opt,
                                                   uint32_t* tile_queue_opt, int32_t hub_threshold, const int32_t* hub_rows,
                                                   int64_t n_hubs, const int32_t* hub_seg_ptr, const int32_t* seg_bounds,
-                                                  const int32_t* seg_node, int64_t n_segments, void* ws, size_t ws_bytes,
-                                                  void* stream) {
+                                                  const int32_t* seg_node, int64_t n_segments, float* alpha_opt,
+                                                  void* ws, size_t ws_bytes, void* stream) {
   if (!h_t2s || !h_s2t || !a_t2s || !a_s2t || !rowptr || !col || !mask || !out) return BGNN_E_NULL;
+  if (alpha_opt && heads != 1) return BGNN_E_SHAPE;
   if (n_hubs > 0 && (!hub_rows || !hub_seg_ptr || !seg_bounds || !seg_node || !ws)) return BGNN_E_NULL;
   if (N < 0 || D <= 0 || D > 256 || ldh < D || ldo < D || (ldh & 3) || (ldo & 3) || hub_threshold < 2 || n_hubs < 0 || n_segments < n_hubs)
     return BGNN_E_SHAPE;
@@ -1023,7 +1029,7 @@ extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const floa
   hipStream_t st = (hipStream_t)stream;
   const int part = (state_ms_opt && heads > 1) ? 3 : 0;
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, 0, N, D, negative_slope,
-              out, ldo, nullptr, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part,
+              out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part,
               0, 4};
   p.hub_threshold = n_hubs > 0 ? hub_threshold : 0;
   if (tile_queue_opt) {
@@ -1038,7 +1044,7 @@ extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const floa
   int rc = dispatch_aggregate(p, st);
   if (rc || n_hubs == 0) return rc;
   HubMergeParams mp{hub_rows, hub_seg_ptr, n_hubs, part_acc, part_ms, mask, D, ldo, heads, out, ep_scale_opt, ep_shift_opt,
-                    ep_relu, colsum_opt, part == 3 ? state_ms_opt : nullptr};
+                    ep_relu, colsum_opt, part == 3 ? state_ms_opt : nullptr, alpha_opt, rowptr};
   if (heads > 1) {
     hipLaunchKernelGGL(hub_merge_heads_kernel, dim3((unsigned)((n_hubs * heads + 255) / 256)), dim3(256), 0, st, mp);
   } else {

@@ -451,7 +451,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
     if row_end <= int(row_begin):                    # empty row range (e.g. no boundary rows at world size 1)
         return (out, alpha) if want_alpha else out
     # graphs with hub rows: segments + merge (bgnn.h).  Whole-graph, single-launch calls of the two hub-aware kernels only.
-    if (not want_alpha and part in (0, 3) and int(row_begin) == 0 and row_end == csr.num_nodes == n_dst and h_t2s.shape[0] == n_dst
+    if ((not want_alpha or heads == 1) and part in (0, 3) and int(row_begin) == 0 and row_end == csr.num_nodes == n_dst and h_t2s.shape[0] == n_dst
             and (ep_scale is None or heads == 1) and _hub_shape_ok(D, ldh, out.stride(0) // heads, heads, negative_slope)
             and os.environ.get("BGNN_HUB_ROWS", "1") != "0"):
         hubs = csr.hub_tables()
@@ -466,9 +466,9 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
                 L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0),
                 L.ptr(state_ms) if part == 3 else None, int(heads), L.ptr(colsum),
                 L.ptr(_tile_queue(dev)) if heads == 1 else None, HUB_THRESHOLD, L.ptr(hub_rows), int(hub_rows.numel()),
-                L.ptr(seg_ptr), L.ptr(seg_bounds), L.ptr(seg_node), nseg, L.ptr(ws), wsb, L.stream())
+                L.ptr(seg_ptr), L.ptr(seg_bounds), L.ptr(seg_node), nseg, L.ptr(alpha), L.ptr(ws), wsb, L.stream())
             L.check(rc, "bgnn_adaptedconv_aggregate_hub_f32")
-            return out
+            return (out, alpha) if want_alpha else out
     rc = lib.bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),

@@ -233,7 +233,8 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
  * all other rows.  Rows with >= hub_threshold in-edges (hub_rows [n_hubs], ascending) are skipped by the main launch, walked as
  * segments -- seg_bounds [2 n_segments] = (begin, end) offsets into `col`, seg_node [n_segments] = the segment's row,
  * hub_seg_ptr [n_hubs + 1] = the segments of each hub -- whose online-softmax states are parked like two-part rows, and finished
- * by a merge launch (normalise, epilogue, colsum; part-3 state for the heads backward when state_ms_opt is given).  All N rows,
+ * by a merge launch (normalise, epilogue, colsum; part-3 state for the heads backward when state_ms_opt is given; alpha_opt [E'],
+ * heads = 1: the attention coefficients in CSR order for the backward).  All N rows,
  * wide rows (D > 32, heads = 1) or interleaved narrow heads (heads = 2 | 3, ldh = ldo = 4); other shapes: BGNN_E_SHAPE (use
  * bgnn_adaptedconv_aggregate_f32).  n_hubs = 0 is the plain launch.  ws: bgnn_aggregate_hub_workspace_bytes(n_segments, heads, ldo). */
 size_t bgnn_aggregate_hub_workspace_bytes(int64_t n_segments, int32_t heads, int64_t ldo);
@@ -245,8 +246,8 @@ int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const float* h_s2t, i
                                        float* state_ms_opt, int32_t heads, double* colsum_opt,
                                        uint32_t* tile_queue_opt, int32_t hub_threshold, const int32_t* hub_rows,
                                        int64_t n_hubs, const int32_t* hub_seg_ptr, const int32_t* seg_bounds,
-                                       const int32_t* seg_node, int64_t n_segments, void* ws, size_t ws_bytes,
-                                       void* stream);
+                                       const int32_t* seg_node, int64_t n_segments, float* alpha_opt,
+                                       void* ws, size_t ws_bytes, void* stream);
 
 /*  backward of the aggregation above -- what autograd computes through
  * models/KTGNN.py:292-305 when main_graph_knowledge_transfer.py:39-68 calls loss.backward().

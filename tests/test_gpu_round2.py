@@ -355,6 +355,12 @@ def test_hub_rows_segments_equal_the_single_walk(D, heads, monkeypatch):
     if ms_h is not None:
         # the softmax state of a hub row: same max, sum within rounding
         assert torch.equal(ms_h[:, :, 0], ms_p[:, :, 0]) and torch.allclose(ms_h[:, :, 1], ms_p[:, :, 1], rtol=1e-5)
+    if heads == 1:                               # the training forward: attention coefficients of the hub rows' edges too
+        o_h, al_h = ops.adaptedconv_aggregate(t1, t2, a1, a2, csr, m8, D, 0.1, want_alpha=True)
+        monkeypatch.setenv("BGNN_HUB_ROWS", "0")
+        o_p, al_p = ops.adaptedconv_aggregate(t1, t2, a1, a2, csr, m8, D, 0.1, want_alpha=True)
+        monkeypatch.delenv("BGNN_HUB_ROWS")
+        assert torch.allclose(al_h, al_p, rtol=2e-5, atol=1e-9) and float((o_h - o_p).abs().max()) <= 2e-6 * max(float(o_p.abs().max()), 1.0)
     if heads == 1:                               # vs the C oracle (fp64 truth of the same fp32 tables), without epilogue
         out_raw = ops.adaptedconv_aggregate(t1, t2, a1, a2, csr, m8, D, 0.1)
         ref = OC.adaptedconv_aggregate_f64(t1[:, :D].contiguous().cpu().numpy(), t2[:, :D].contiguous().cpu().numpy(), a1.cpu().numpy(),
