@@ -272,6 +272,87 @@ def test_c4_full_size_forward_real_attention_vs_oracle():
     assert np.allclose(sums, [float(np.asarray(r, np.float64).sum()) for r in (rb, rt, rth)], rtol=1e-6)
 
 
+def test_c4_full_size_aggregation_backward_vs_torch_autograd():
+    """Row f1 at the size the bench times: the hidden conv's aggregation (D = 128, pull-form backward, hub segments where the
+    graph has them) and the three D = 2 classifier heads in one walk (log_softmax epilogue), forward + backward on the bench's
+    own 1M-node / 21M-edge graph, against torch autograd of the reference's op sequence (index_select / leaky_relu / segment
+    softmax / index_add, KTGNN.py:292-305) on the SAME fp32 tables on the GPU (so no leaky-relu kink can flip between the
+    sides).  Bars: 5e-6 of the tensor's max for outputs and table gradients (measured <= 6e-7), 1e-4 for the attention vectors'
+    gradients (sums over all 21M edges, fp32 atomics in an unordered sequence on BOTH sides; measured 7e-6 .. 3e-5)."""
+    import argparse
+    import torch.nn.functional as F
+    import bench
+    from bridged_gnn_amd import ops
+    from bridged_gnn_amd.ktgnn import _AggregateFn, _AggregateHeadsFn
+    args = argparse.Namespace(config="c4", nodes=1_000_000, edges=20_000_000, graph="local", feat=128, hidden=128, classes=2)
+    wl = bench.make_workload(args, torch.device(DEV))
+    ei, mask = wl["ei_np"], wl["mask_np"]
+    n = mask.shape[0]
+    csr = ops.build_dst_csr(_t(ei), n)
+    assert csr.num_edges == 20_991_058
+    m8 = _t(mask).to(torch.uint8)
+    e1, e2 = (e.to(DEV) for e in OT.graph_partition(torch.from_numpy(ei), torch.from_numpy(mask)))
+    dst = torch.cat((e1[1], e2[1]))
+    n1 = e1.shape[1]
+
+    def seg_softmax(z):
+        m = torch.full((n,), float("-inf"), device=DEV).scatter_reduce(0, dst, z, reduce="amax", include_self=True)
+        e = (z - m[dst]).exp()
+        return e / (torch.zeros(n, device=DEV).index_add_(0, dst, e)[dst] + 1e-16)
+
+    def ref_conv(t1, t2, b1, b2):
+        z = torch.cat((F.leaky_relu(t1[e1[0]] + t1[e1[1]], 0.1) @ b1, F.leaky_relu(t2[e2[0]] + t2[e2[1]], 0.1) @ b2))
+        al = seg_softmax(z)
+        o = torch.zeros(n, t1.shape[1], device=DEV)
+        return o.index_add(0, e1[1], t1[e1[0]] * al[:n1, None]).index_add(0, e2[1], t2[e2[0]] * al[n1:, None])
+
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    g = torch.Generator(device=DEV).manual_seed(11)
+    # ---- hidden conv: D = 128
+    D = 128
+    T = [torch.randn(n, D, device=DEV, generator=g) for _ in range(2)]
+    A = [torch.randn(D, device=DEV, generator=g) * 0.1 for _ in range(2)]
+    w = torch.randn(n, D, device=DEV, generator=g)
+    mine = [t.clone().requires_grad_(True) for t in T + A]
+    out = _AggregateFn.apply(mine[0], mine[1], mine[2], mine[3], csr, m8, D, 0.1)
+    (out[:, :D] * w).sum().backward()
+    theirs = [t.clone().requires_grad_(True) for t in T + A]
+    o = ref_conv(*theirs)
+    (o * w).sum().backward()
+    errs = {"out": rel(out[:, :D].detach(), o.detach())}
+    for name, a, b in zip(("dh_t2s", "dh_s2t", "da_t2s", "da_s2t"), mine, theirs):
+        errs[name] = rel(a.grad, b.grad)
+    print("C4 full size, D=128:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs["out"], errs["dh_t2s"], errs["dh_s2t"]) < 5e-6, errs       # measured 2.4e-7 .. 3.8e-7
+    assert max(errs["da_t2s"], errs["da_s2t"]) < 1e-4, errs
+    del out, o, mine, theirs, T, w
+    torch.cuda.empty_cache()
+    # ---- the three classifier heads: D = 2, tables [N, 4] per head, log_softmax in the epilogue (KTGNN.py:432-435)
+    D, H = 2, 3
+    tabs = []
+    for _ in range(2 * H):
+        t = torch.zeros(n, 4, device=DEV)
+        t[:, :D] = torch.randn(n, D, device=DEV, generator=g)
+        tabs.append(t)
+    a_t = torch.randn(H, D, device=DEV, generator=g) * 0.5
+    a_s = torch.randn(H, D, device=DEV, generator=g) * 0.5
+    w = torch.randn(n, H, D, device=DEV, generator=g)
+    mine = [t.clone().requires_grad_(True) for t in [a_t, a_s] + tabs]
+    lp = _AggregateHeadsFn.apply(csr, m8, D, 0.1, *mine)                     # [N, H, 4]
+    (lp[:, :, :D] * w).sum().backward()
+    theirs = [t.clone().requires_grad_(True) for t in [a_t, a_s] + tabs]
+    ref = torch.stack([torch.log_softmax(ref_conv(theirs[2 + 2 * h][:, :D], theirs[3 + 2 * h][:, :D], theirs[0][h], theirs[1][h]), 1)
+                       for h in range(H)], dim=1)                            # [N, H, D]
+    (ref * w).sum().backward()
+    errs = {"logp": rel(lp[:, :, :D].detach(), ref.detach()), "da_t2s": rel(mine[0].grad, theirs[0].grad), "da_s2t": rel(mine[1].grad, theirs[1].grad)}
+    for i in range(2 * H):
+        errs[f"dtab{i}"] = rel(mine[2 + i].grad[:, :D], theirs[2 + i].grad[:, :D])
+        assert float(mine[2 + i].grad[:, D:].abs().max()) == 0.0             # padding columns get no gradient
+    print("C4 full size, 3 heads D=2:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(v for k, v in errs.items() if not k.startswith("da_")) < 5e-6, errs      # measured 1.6e-7 .. 5.7e-7
+    assert max(errs["da_t2s"], errs["da_s2t"]) < 1e-4, errs
+
+
 def test_input_domain_sums_cache_follows_x():
     """the cached domain sums of the (static) input features are dropped when x is written in place or replaced"""
     from bridged_gnn_amd import synth
