@@ -669,8 +669,41 @@ __global__ __launch_bounds__(256, 1) void mlp_pass1_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // canonical scores (identical arithmetic to oracle/oracle_c.c)
+// a double from lane `J` of every quad (DPP quad_perm broadcast, two 32-bit moves)
+template <int J>
+__device__ __forceinline__ double quad_bcast_f64(double v) {
+  constexpr int CTRL = J | (J << 2) | (J << 4) | (J << 6);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+
 struct CosineCanon {
   const float* qq; const float* qc; int d;
+  static constexpr bool COOP4 = true;
+  // The same sum, evaluated by a QUAD of lanes for one candidate: lane j holds floats 16i + 4j .. + 3 of both rows, so one load
+  // instruction of the quad covers one 64-byte line (a lane walking "its" row alone touches a line per lane and instruction, and
+  // the refine stage was bound by that request rate).  The running sum visits the elements in index order: within a line lane 0's
+  // four terms, then lane 1's, ... -- every lane adds its own terms to the current sum and the quad takes lane jj's result, so
+  // the sequence of fp64 additions is exactly operator()'s (bit-identical; d % 16 == 0).  Returns the sum in all four lanes.
+  __device__ __forceinline__ double coop4(int64_t q, int64_t c, int j) const {
+    const float* a = qq + q * d + 4 * j;
+    const float* b = qc + c * d + 4 * j;
+    double s = 0.0;
+    for (int t = 0; t < d; t += 16) {
+      const float4 x = *reinterpret_cast<const float4*>(a + t);
+      const float4 y = *reinterpret_cast<const float4*>(b + t);
+      const double p0 = (double)x.x * (double)y.x, p1 = (double)x.y * (double)y.y;      // exact
+      const double p2 = (double)x.z * (double)y.z, p3 = (double)x.w * (double)y.w;
+      double r;
+      r = s + p0; r = r + p1; r = r + p2; r = r + p3; s = quad_bcast_f64<0>(r);
+      r = s + p0; r = r + p1; r = r + p2; r = r + p3; s = quad_bcast_f64<1>(r);
+      r = s + p0; r = r + p1; r = r + p2; r = r + p3; s = quad_bcast_f64<2>(r);
+      r = s + p0; r = r + p1; r = r + p2; r = r + p3; s = quad_bcast_f64<3>(r);
+    }
+    return s;
+  }
   __device__ __forceinline__ double operator()(int64_t q, int64_t c) const {
     const float* a = qq + q * d;
     const float* b = qc + c * d;
@@ -688,6 +721,8 @@ struct CosineCanon {
 };
 struct MlpCanon {
   const float* A; const float* B; const float* scale; const float* shift; const float* w2; float b2; int H;
+  static constexpr bool COOP4 = false;
+  __device__ __forceinline__ double coop4(int64_t, int64_t, int) const { return 0.0; }
   __device__ __forceinline__ double operator()(int64_t q, int64_t c) const {
     const float* a = A + c * H;
     const float* b = B + q * H;
@@ -786,12 +821,22 @@ __global__ __launch_bounds__(256) void refine_kernel(Canon canon, const RefinePa
       if (surv) {
         const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
         ei[pos] = c;                                  // pos <= e: packing in place is safe chunk by chunk
-        es[pos] = canon(q, c);
+        if constexpr (!Canon::COOP4) es[pos] = canon(q, c);
       }
       ns += __popcll(b);
     }
     __builtin_amdgcn_s_waitcnt(0);   // LDS writes above complete before the cross-lane reads below
     __builtin_amdgcn_wave_barrier();
+    if constexpr (Canon::COOP4) {
+      // 16 survivors per step, a quad of lanes each (Canon::coop4); idle quads re-score survivor 0 (in-bounds, discarded)
+      for (int e0 = 0; e0 < ns; e0 += 16) {
+        const int e = e0 + (lane >> 2);
+        const double sc = canon.coop4(q, (int64_t)ei[e < ns ? e : 0], lane & 3);
+        if (e < ns && (lane & 3) == 0) es[e] = sc;
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
     double kth = -INFINITY;
     for (int e = lane; e < ns; e += 64) {
       const double s = es[e];
