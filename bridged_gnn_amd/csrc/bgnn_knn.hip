@@ -937,17 +937,19 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
   const float* src = q + r0 * d;
   for (int t = tid; t < total; t += 256) nrm_tile[(t / d) * ld + (t % d)] = src[t];
   __syncthreads();
+  __shared__ float nrm_len[64];                     // NORM_ROWS <= 64 (host)
   if (tid < nrows) {
-    float* r = nrm_tile + tid * ld;
+    const float* r = nrm_tile + tid * ld;
     double s = 0.0;
     for (int c = 0; c < d; ++c) { const double v = (double)r[c]; s = s + v * v; }
     float nr = (float)sqrt(s);
     if (!(nr > eps)) nr = eps;
-    for (int c = 0; c < d; ++c) r[c] = __fdiv_rn(r[c], nr);
+    nrm_len[tid] = nr;
   }
   __syncthreads();
+  // the divisions are element-wise (no order to keep): all 256 threads, straight into the coalesced store
   float* dst = out + r0 * d;
-  for (int t = tid; t < total; t += 256) dst[t] = nrm_tile[(t / d) * ld + (t % d)];
+  for (int t = tid; t < total; t += 256) dst[t] = __fdiv_rn(nrm_tile[(t / d) * ld + (t % d)], nrm_len[t / d]);
 }
 
 __global__ void normalize_rows_wide_kernel(const float* __restrict__ q, int64_t n, int d, float eps, float* __restrict__ out) {
