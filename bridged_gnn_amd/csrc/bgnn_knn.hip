@@ -322,7 +322,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
     *reinterpret_cast<bf16x4*>(hi + row * d + c4 * 4) = h;
     *reinterpret_cast<bf16x4*>(mid + row * d + c4 * 4) = m;
-    for (int o = 1; o < lpr; o <<= 1) { r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); }   // the lanes of a row share its trip count
+    // sums over the lanes of the row (they share its trip count) through DPP moves, not LDS permutes; the order of these
+    // fp32 additions is covered by knn_eps's inflation factor
+    switch (lpr) {
+      case 8: r1 = bgnn::group_sum<8>(r1); r2 = bgnn::group_sum<8>(r2); break;
+      case 16: r1 = bgnn::group_sum<16>(r1); r2 = bgnn::group_sum<16>(r2); break;
+      case 32: r1 = bgnn::group_sum<32>(r1); r2 = bgnn::group_sum<32>(r2); break;
+      default: r1 = bgnn::group_sum<64>(r1); r2 = bgnn::group_sum<64>(r2); break;
+    }
     M1 = fmaxf(M1, r1); M2 = fmaxf(M2, r2);
   }
   for (int o = 32; o > 0; o >>= 1) { M1 = fmaxf(M1, __shfl_xor(M1, o)); M2 = fmaxf(M2, __shfl_xor(M2, o)); }
