@@ -521,7 +521,12 @@ def main():
         t0 = time.perf_counter()
         csr = model._prepare(data)
         torch.cuda.synchronize()
-        csr_ms = (time.perf_counter() - t0) * 1e3
+        csr_first_ms = (time.perf_counter() - t0) * 1e3          # first call of the process: allocations + code-object load
+        from bridged_gnn_amd import ops as _ops
+        t0 = time.perf_counter()
+        _ops.build_dst_csr(data.edge_index, N)
+        torch.cuda.synchronize()
+        csr_ms = (time.perf_counter() - t0) * 1e3                # the build itself (one-time per graph, cached by the model)
         Eprime = csr.num_edges
         runner = lambda: model(data)
         par = "single"
@@ -531,7 +536,7 @@ def main():
         pk = PartitionedKTGNN(model, ei_np, mask_np, rank, world, dev, always_communicate=args.force_dist,
                               cache_input_halo=not args.no_input_halo_cache)
         torch.cuda.synchronize()
-        csr_ms = (time.perf_counter() - t0) * 1e3
+        csr_ms = csr_first_ms = (time.perf_counter() - t0) * 1e3   # (partition plan + the rank's two CSRs, first call)
         Eprime = pk.global_num_edges
         x_local = wl["x"][pk.owned_global].contiguous()          # the same seed on every rank
         wl["x"] = None
@@ -634,7 +639,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl['name']} N={N} E'={Eprime}, 2-layer KT-GNN eval fwd F={args.feat} hidden={args.hidden} C={args.classes}",
-                       "parallelism": par, "csr_build_ms": csr_ms},
+                       "parallelism": par, "csr_build_ms": csr_ms, "csr_build_first_call_ms": csr_first_ms},
             "hidden_conv_edges_per_sec": e_local * world / (agg_ms * 1e-3),
             "roofline": roof,
             "output_checksums": {"what": "fp64 sums of the three log-prob outputs of the timed forward" +
