@@ -613,6 +613,26 @@ def main():
                  "what": "SURVEY 8(f) rank 1, reported beside the headline (not part of `value`): train-mode forward (dropout 0.5, batch-stat "
                          "BatchNorm) + backward (HIP kernels: pull aggregation backward, fused BN/ReLU/dropout, prep / bf16x3 Gram / "
                          "W-stationary transform backward) + fused Adam, reference loss (main_graph_knowledge_transfer.py:44-54)"}
+        if args.config in ("c2", "c3"):
+            # the reference's own graph sizes: a step is ~170 short launches and host-bound -> one HIP graph per step
+            try:
+                gmodel = copy.deepcopy(model).train()
+                gopt = torch.optim.Adam(gmodel.parameters(), lr=1e-3, weight_decay=5e-3, capturable=True)
+
+                def loss_fn(o):
+                    lb, lt, lth, _ = o
+                    return (2 * nll(lb, w_b) + nll(lt, w_t) + nll(lth, w_t)) / 4 + F.kl_div(lth, lt, log_target=True, reduction="batchmean")
+                run = gmodel.graphed_train_step(data, loss_fn, gopt)
+                run(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10 * args.train_steps):
+                    run()
+                torch.cuda.synchronize()
+                train["graph_replay_ms_per_train_step"] = (time.perf_counter() - t0) / (10 * args.train_steps) * 1e3
+                train["graph_replay_loss"] = float(run().detach())
+                del gmodel, gopt, run
+            except Exception as e:                                   # reported, not fatal: the eager number stands
+                train["graph_replay_ms_per_train_step"] = f"capture failed: {type(e).__name__}: {str(e)[:160]}"
         del tmodel, opt
     knn = knn_bench(args, dev, rank, world) if (not args.no_knn and args.config == "c4") else None   # every rank takes part
     out = None

@@ -35,8 +35,8 @@ SIGNATURES = {
     "bgnn_transform_bwd_prep_workspace_bytes": (C.c_size_t, [_I64, _I32]),
     "bgnn_transform_bwd_prep_f32": (_INT, [_P, _I64, _I64, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _I64, _P, _I64, _P, _P, C.c_size_t, _P]),
     "bgnn_bn_acc_doubles": (_I64, [_I32]),
-    "bgnn_bn_relu_dropout_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _F32, _INT, _F32, C.c_uint64, _F32, _P, _P, _P, _I64, _P, _P]),
-    "bgnn_bn_relu_dropout_bwd_f32": (_INT, [_P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _F32, _INT, _F32, C.c_uint64, _P, _I64, _P, _P]),
+    "bgnn_bn_relu_dropout_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _F32, _INT, _F32, C.c_uint64, _P, _F32, _P, _P, _P, _I64, _P, _P]),
+    "bgnn_bn_relu_dropout_bwd_f32": (_INT, [_P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _F32, _INT, _F32, C.c_uint64, _P, _P, _I64, _P, _P]),
     "bgnn_transform_bwd_consts_f32": (_INT, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "bgnn_transform_bwd_finish_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "bgnn_rowdot_f32": (_INT, [_P, _I64, _I64, _I32, _P, _I64, _I32, _P, _P]),

@@ -992,7 +992,7 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
               park_begin, 4};
   hipStream_t st = (hipStream_t)stream;
   if (tile_queue_opt) {
-    hipError_t e = hipMemsetAsync(tile_queue_opt, 0, 8 * sizeof(uint32_t), st);
+    hipError_t e = bgnn_zero_async(tile_queue_opt, 8 * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
   }
   return dispatch_aggregate(p, st);
@@ -1033,7 +1033,7 @@ extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const floa
               0, 4};
   p.hub_threshold = n_hubs > 0 ? hub_threshold : 0;
   if (tile_queue_opt) {
-    hipError_t e = hipMemsetAsync(tile_queue_opt, 0, 8 * sizeof(uint32_t), st);
+    hipError_t e = bgnn_zero_async(tile_queue_opt, 8 * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
   }
   float* part_acc = n_hubs > 0 ? (float*)ws : nullptr;
@@ -1069,7 +1069,7 @@ extern "C" int bgnn_tune_aggregate(const float* h_t2s, const float* h_s2t, int64
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, slope,
               out, ldo, nullptr, nullptr, nullptr, 0, tile_queue, nullptr, 1, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (tile_queue && hipMemsetAsync(tile_queue, 0, 32, st) != hipSuccess) return -1;
+  if (tile_queue && bgnn_zero_async(tile_queue, 32, st) != hipSuccess) return -1;
   switch (variant) {
     case 40: return launch_wide<32, 4>(p, st);
     case 41: return launch_wide<32, 8>(p, st);

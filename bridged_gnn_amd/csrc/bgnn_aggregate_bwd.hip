@@ -904,7 +904,7 @@ static int pull_impl(const float* h_t2s, const float* h_s2t, int64_t ldh, const 
     p.s_vnode = s_vnode; p.s_vbounds = s_vbounds; p.s_nv = s_nv; p.s_vpartS = seg + (size_t)d_nv * ldh; p.s_vpartT = seg + (size_t)(d_nv + s_nv) * ldh;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(queue, 0, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (bgnn_zero_async(queue, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (narrow) return launch_pull_narrow(p, st);
   const int nv = (D + 3) / 4;
   if (nv <= 2) return launch_pull<2>(p, st, hubs);

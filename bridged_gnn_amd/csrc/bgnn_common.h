@@ -25,6 +25,21 @@ static inline hipError_t bgnn_set_max_dynamic_lds(const void* fn, int bytes, int
   return e;
 }
 
+// Zero-fill of device scratch as a kernel of our own, not hipMemsetAsync: inside a captured HIP graph (ROCm 7.2) the memset node
+// of a small region replayed correctly back to back, but after eager work between two replays it filled the region with a stale
+// pattern (pointer-like words) instead of zeros -- the aggregation's tile counters then started from garbage
+// (tools/graph_agg_probe2.py).  `bytes` % 4 == 0, `p` 4-byte aligned.
+static __global__ void bgnn_zero_words_kernel(uint32_t* __restrict__ p, size_t nwords) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t bgnn_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t nwords = bytes / 4;
+  if (nwords == 0) return hipSuccess;
+  const size_t blocks = (nwords + 255) / 256;
+  hipLaunchKernelGGL(bgnn_zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, (uint32_t*)p, nwords);
+  return hipGetLastError();
+}
+
 static inline bool bgnn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t bgnn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -655,7 +655,7 @@ extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t 
   if (!bgnn_aligned16(x) || !bgnn_aligned16(gx) || (side_opt && !bgnn_aligned16(side_opt))) return BGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
-    if (ex_opt && hipMemsetAsync(ex_opt, 0, sizeof(float) * 4 * (size_t)p, st) != hipSuccess) return (int)hipErrorInvalidValue;
+    if (ex_opt && bgnn_zero_async(ex_opt, sizeof(float) * 4 * (size_t)p, st) != hipSuccess) return (int)hipErrorInvalidValue;
     return 0;
   }
   const int grid = prep_blocks(N, ex_opt != nullptr);

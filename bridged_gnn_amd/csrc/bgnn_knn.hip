@@ -1148,8 +1148,8 @@ extern "C" int bgnn_cosine_topk_f32(const float* qn_query, const float* qn_cand,
   TopkWs w;
   topk_ws_layout(Nq, Nc, k, d, &w, ws);
   hipError_t e;
-  if ((e = hipMemsetAsync(w.counts, 0, 256, st)) != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(w.mx, 0, 256, st)) != hipSuccess) return (int)e;
+  if ((e = bgnn_zero_async(w.counts, 256, st)) != hipSuccess) return (int)e;
+  if ((e = bgnn_zero_async(w.mx, 256, st)) != hipSuccess) return (int)e;
   // stage 0: bf16 pieces + residual maxima
   const int lpr = d / 4;
   auto split_grid = [&](int64_t n) { const int64_t g = (n * lpr + 255) / 256; return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024); };
@@ -1235,7 +1235,7 @@ extern "C" int bgnn_mlp_pair_topk_f32(const float* A_cand, const float* B_query,
   TopkWs w;
   topk_ws_layout(Nq, Nc, k, 32, &w, ws);
   hipError_t e;
-  if ((e = hipMemsetAsync(w.counts, 0, 256, st)) != hipSuccess) return (int)e;
+  if ((e = bgnn_zero_async(w.counts, 256, st)) != hipSuccess) return (int)e;
   // fp32 evaluation of a 128-term sum of O(1) terms: relative bound on the logit magnitude plus an absolute floor;
   // generous (a loose bound only widens the shortlist / costs a few more exhaustive rows)
   const float err_abs = 1e-4f, err_rel = 1e-4f;

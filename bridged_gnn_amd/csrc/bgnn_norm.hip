@@ -30,6 +30,7 @@ struct NormParams {
   const double* stats;          // [2 * D]: sum x | sum x^2
   const float* gamma; const float* beta; float eps;
   int relu; uint32_t thr; float keep_scale; uint64_t seed;
+  const uint64_t* seed_dev;     // optional device word added to `seed` (a captured HIP graph bakes `seed` in; the word moves per replay)
   float* y; int64_t ldy;
   float momentum; float* running_mean; float* running_var;   // updated by block 0 when non-null
   const float* gy; int64_t ldg; double* gsum;                 // backward: [2 * D]: sum g' | sum g'.xhat
@@ -113,6 +114,7 @@ __device__ __forceinline__ void col_consts(const NormParams& p, const double* st
 }
 
 __global__ __launch_bounds__(NT) void bn_apply_kernel(NormParams p) {
+  if (p.seed_dev != nullptr) p.seed += *p.seed_dev;
   const Lay l = lay_of(p.D);
   __shared__ double st[2 * MAXD];
   block_totals(p.stats, p.D, st);
@@ -163,6 +165,7 @@ __device__ __forceinline__ void grad_prime(const NormParams& p, const Lay& l, in
 }
 
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(NormParams p) {
+  if (p.seed_dev != nullptr) p.seed += *p.seed_dev;
   const Lay l = lay_of(p.D);
   __shared__ double st[2 * MAXD];
   block_totals(p.stats, p.D, st);
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(NormParams p) {
 }
 
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(NormParams p) {
+  if (p.seed_dev != nullptr) p.seed += *p.seed_dev;
   const Lay l = lay_of(p.D);
   __shared__ double st[2 * MAXD], gs[2 * MAXD];
   block_totals(p.stats, p.D, st);
@@ -228,7 +232,7 @@ void drop_consts(float p_drop, uint32_t& thr, float& scale) {
 extern "C" int64_t bgnn_bn_acc_doubles(int32_t D) { return (int64_t)acc_doubles(D > 0 ? D : 0); }
 
 extern "C" int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, int64_t ldx, const float* gamma_opt,
-                                        const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed,
+                                        const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed, const uint64_t* seed_dev_opt,
                                         float momentum, float* running_mean_opt, float* running_var_opt,
                                         float* y, int64_t ldy, double* stats, void* stream) {
   if (!x || !y || !stats) return BGNN_E_NULL;
@@ -236,11 +240,11 @@ extern "C" int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, in
   if (!shape_ok(N, D, ldx) || !shape_ok(N, D, ldy) || !(p_drop >= 0.f && p_drop < 1.f)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(y)) return BGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(stats, 0, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (bgnn_zero_async(stats, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (N == 0) return 0;
   NormParams p{};
   p.x = x; p.N = N; p.D = D; p.ldx = ldx; p.stats = stats; p.gamma = gamma_opt; p.beta = beta_opt; p.eps = eps;
-  p.relu = relu; p.seed = seed; p.y = y; p.ldy = ldy;
+  p.relu = relu; p.seed = seed; p.seed_dev = seed_dev_opt; p.y = y; p.ldy = ldy;
   p.momentum = momentum; p.running_mean = running_mean_opt; p.running_var = running_var_opt;
   drop_consts(p_drop, p.thr, p.keep_scale);
   const int grid = grid_for(N, D);
@@ -253,17 +257,17 @@ extern "C" int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, in
 
 extern "C" int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y, int64_t N, int32_t D, int64_t ldx, int64_t ldg,
                                             const double* stats, const float* gamma_opt, const float* beta_opt, float eps,
-                                            int relu, float p_drop, uint64_t seed, float* grad_x, int64_t ldgx,
+                                            int relu, float p_drop, uint64_t seed, const uint64_t* seed_dev_opt, float* grad_x, int64_t ldgx,
                                             double* gsum, void* stream) {
   if (!x || !grad_y || !stats || !grad_x || !gsum) return BGNN_E_NULL;
   if (!shape_ok(N, D, ldx) || !shape_ok(N, D, ldg) || !shape_ok(N, D, ldgx) || !(p_drop >= 0.f && p_drop < 1.f)) return BGNN_E_SHAPE;
   if (!bgnn_aligned16(x) || !bgnn_aligned16(grad_y) || !bgnn_aligned16(grad_x)) return BGNN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(gsum, 0, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
+  if (bgnn_zero_async(gsum, sizeof(double) * acc_doubles(D), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (N == 0) return 0;
   NormParams p{};
   p.x = x; p.N = N; p.D = D; p.ldx = ldx; p.stats = stats; p.gamma = gamma_opt; p.beta = beta_opt; p.eps = eps;
-  p.relu = relu; p.seed = seed; p.gy = grad_y; p.ldg = ldg; p.gsum = gsum; p.gx = grad_x; p.ldgx = ldgx;
+  p.relu = relu; p.seed = seed; p.seed_dev = seed_dev_opt; p.gy = grad_y; p.ldg = ldg; p.gsum = gsum; p.gx = grad_x; p.ldgx = ldgx;
   drop_consts(p_drop, p.thr, p.keep_scale);
   const int grid = grid_for(N, D);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(NT), 0, st, p);

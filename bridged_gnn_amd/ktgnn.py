@@ -61,7 +61,11 @@ class _LinearFn(torch.autograd.Function):
             ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                   and x.data_ptr() % 16 == 0 and ops.gram_supported(gy.shape[1], x.shape[1]) and x.shape[0] >= 4096)
             gw = ops.gram(gy, x) if ok else gy.t() @ x
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ok = (gy.is_cuda and gy.dtype == torch.float32 and gy.shape[1] % 4 == 0 and gy.stride(1) == 1 and gy.stride(0) % 4 == 0
+                  and gy.data_ptr() % 16 == 0)
+            gb = ops.column_sums(gy) if ok else gy.sum(0)
         return gx, gw, gb
 
 
@@ -134,6 +138,11 @@ def _pad_cols4(t):
     return t.contiguous() if pad == 0 else F.pad(t, (0, pad)).contiguous()
 
 
+# int64 device tensor [1] added to every dropout seed inside the kernels while a training step is being captured
+# (KTGNN_no_complement.graphed_train_step advances it once per replay); None in eager mode
+_DROPOUT_STEP = [None]
+
+
 class _BnReluDropFn(torch.autograd.Function):
     """Training-mode `BatchNorm1d` -> `F.relu` -> `F.dropout` (KTGNN.py:420-430; clf_transformer's BN + ReLU with p = 0) as
     two streaming HIP launches forward and two backward (torch: eight launches and three saved [N, D] intermediates).
@@ -150,9 +159,11 @@ class _BnReluDropFn(torch.autograd.Function):
             mom = bn.momentum              # (momentum None = cumulative average: left to torch, see bn_relu_dropout_train)
         y, stats = ops.bn_relu_dropout(x, weight.detach() if weight is not None else None,
                                        bias.detach() if bias is not None else None, bn.eps, relu, p_drop, seed, mom,
-                                       bn.running_mean if track else None, bn.running_var if track else None)
+                                       bn.running_mean if track else None, bn.running_var if track else None,
+                                       seed_dev=_DROPOUT_STEP[0])
         ctx.save_for_backward(x, weight, bias, stats)
         ctx.cfg = (bn.eps, relu, p_drop, seed)
+        ctx.seed_dev = _DROPOUT_STEP[0]
         return y
 
     @staticmethod
@@ -161,7 +172,8 @@ class _BnReluDropFn(torch.autograd.Function):
         eps, relu, p_drop, seed = ctx.cfg
         gy = gy if (gy.stride(1) == 1 and gy.stride(0) % 4 == 0 and gy.data_ptr() % 16 == 0) else gy.contiguous()
         gx, gsum = ops.bn_relu_dropout_bwd(x, gy, stats, weight.detach() if weight is not None else None,
-                                           bias.detach() if bias is not None else None, eps, relu, p_drop, seed)
+                                           bias.detach() if bias is not None else None, eps, relu, p_drop, seed,
+                                           seed_dev=ctx.seed_dev)
         D = x.shape[1]
         gs = gsum.float()
         return (gx if ctx.needs_input_grad[0] else None, gs[D:] if weight is not None else None,
@@ -827,6 +839,65 @@ class KTGNN_no_complement(nn.Module):
             g.replay()
             return out
         replay.graph = g
+        return replay
+
+    def _drop_param_caches(self):
+        """forget every packed / folded copy of the parameters (they are keyed by the parameters' host-side version counters,
+        which a replayed HIP graph does not advance)"""
+        for c in list(self.convs) + [self.clf_base, self.clf_target]:
+            c._pack_key = None
+        self._tf_key = None
+        self._tf_pack = None
+        self._a3_key = None
+
+    def graphed_train_step(self, data, loss_fn, optimizer, warmup=3):
+        """One training step of the reference's loop (main_graph_knowledge_transfer.py:39-68: zero_grad, forward, loss,
+        backward, optimizer.step) captured into ONE HIP graph; returns a zero-argument callable that replays it and returns
+        the loss (a device tensor that every replay overwrites).  On the reference's own graph sizes (1e3-1e4 nodes) a step is
+        ~170 short launches and bound by host launch cost; a replay is one submission.
+        `loss_fn(outputs) -> scalar tensor` gets `self(data)`'s 4-tuple and must stay on the device (no `.item()`, no boolean-mask
+        indexing); `optimizer` must be capturable (e.g. `torch.optim.Adam(..., capturable=True)`).  On ROCm 7.2 a memset NODE of a
+        captured graph replays a stale fill pattern once eager GPU work has run between two replays; this package's kernels clear
+        their scratch with a kernel of their own for that reason, but torch's multi-block reductions (`Tensor.sum()` / `mean()` over
+        more than a few 10^4 elements, `nll_loss` on large inputs) clear a semaphore buffer with such a node -- inside `loss_fn`
+        reduce large tensors with `ops.total_sum` if eager work (an eval pass, say) runs between replays.  The dropout masks differ
+        from replay to replay: the kernels add a device step counter, advanced inside the graph, to the seed baked in at
+        capture.  `data.*` must stay the same tensors with the same contents (re-capture after changing the graph or x: the CSR
+        and the input's domain sums are cached on the host side)."""
+        if not self.training:
+            raise RuntimeError("graphed_train_step() captures a training step; call model.train() first")
+        if any(not g["capturable"] for g in optimizer.param_groups if "capturable" in g):
+            raise RuntimeError("graphed_train_step() needs a capturable optimizer, e.g. torch.optim.Adam(params, capturable=True)")
+        dev = data.x.device
+        step = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        _DROPOUT_STEP[0] = step
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 1)):   # allocations, host-side caches, kernel attributes, optimizer state
+                    step.add_(1)
+                    optimizer.zero_grad(set_to_none=True)
+                    loss_fn(self(data)).backward()
+                    optimizer.step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                step.add_(1)
+                loss = loss_fn(self(data))
+                loss.backward()
+                optimizer.step()
+        finally:
+            _DROPOUT_STEP[0] = None
+        self._drop_param_caches()
+
+        def replay():
+            g.replay()
+            self._drop_param_caches()              # the weights moved; the host-side version counters did not
+            return loss
+        replay.graph, replay.step = g, step
         return replay
 
     def get_emb(self, data):

@@ -124,9 +124,6 @@ class ZeroArena:
         return t
 
 
-_DS_WS = {}
-
-
 def domain_sums(x, mask_u8, out=None, deterministic=False):
     """Per-domain column sums + counts as a float64 [2*Din+2] tensor (all-reducible).  `out`: zero-filled accumulator.
     `deterministic`: the two-stage form (per-block partial rows + a second small launch, no atomics: run-to-run
@@ -140,13 +137,40 @@ def domain_sums(x, mask_u8, out=None, deterministic=False):
         rc = lib.bgnn_domain_sums_f64(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(sums), L.stream())
         L.check(rc, "bgnn_domain_sums_f64")
         return sums
-    key = (x.device.index, L.raw_stream(), Din)
-    ws = _DS_WS.get(key)
-    if ws is None:                                    # per (device, stream, width): launches on one stream are ordered
-        ws = _DS_WS[key] = torch.empty(lib.bgnn_domain_sums_workspace_bytes(Din), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(lib.bgnn_domain_sums_workspace_bytes(Din), dtype=torch.uint8, device=x.device)   # per call (see _tile_queue)
     rc = lib.bgnn_domain_sums_ws_f64(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream())
     L.check(rc, "bgnn_domain_sums_ws_f64")
     return sums
+
+
+def column_sums(x):
+    """sum over the rows of x [N, D] (fp64 accumulation, D % 4 == 0 and a 16-byte aligned, row-contiguous x) -> float32 [D]: the bias
+    gradient of a Linear.  One streaming launch of the domain-sums kernel with every row in one domain; torch's `x.sum(0)` is a
+    multi-block reduction whose semaphore buffer is cleared by a memset node when captured into a HIP graph (see bgnn_zero_async)."""
+    N, D = x.shape
+    mask = torch.zeros(N, dtype=torch.uint8, device=x.device)
+    return domain_sums(x, mask)[D:2 * D].float()
+
+
+def total_sum(x):
+    """sum of all elements of a float32 tensor as a 0-dim float32 tensor, through `column_sums` (no torch multi-block reduction: safe
+    inside a captured training step, see `KTGNN_no_complement.graphed_train_step`).  Differentiable (d/dx = 1)."""
+    return _TotalSumFn.apply(x)
+
+
+class _TotalSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        flat = x.contiguous().view(-1)
+        pad = (-flat.numel()) % 64
+        if pad:
+            flat = torch.cat((flat, flat.new_zeros(pad)))
+        return column_sums(flat.view(-1, 64)).sum()          # 64 values: a single-block reduction
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape)
 
 
 def domain_delta(sums, Din):
@@ -294,15 +318,16 @@ def bn_relu_dropout_supported(x):
             and 4 <= x.shape[1] <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
-def bn_relu_dropout(x, gamma, beta, eps, relu, p_drop, seed, momentum=0.0, running_mean=None, running_var=None):
+def bn_relu_dropout(x, gamma, beta, eps, relu, p_drop, seed, momentum=0.0, running_mean=None, running_var=None, seed_dev=None):
     """Training-mode BatchNorm1d -> ReLU -> dropout (KTGNN.py:420-430) -> (y, stats); `stats` (fp64 column sums of x | x^2)
-    is what the backward needs besides x."""
+    is what the backward needs besides x.  `seed_dev`: optional int64 device tensor [1] added to `seed` inside the kernels (the step
+    counter of a captured training step)."""
     N, D = x.shape
     y = torch.empty(N, D, dtype=torch.float32, device=x.device)
     stats = torch.empty(L.lib().bgnn_bn_acc_doubles(D), dtype=torch.float64, device=x.device)   # R x [2D] partial accumulators
     rc = L.lib().bgnn_bn_relu_dropout_f32(L.ptr_rows(x), N, D, x.stride(0), L.ptr(gamma) if gamma is not None else None,
                                           L.ptr(beta) if beta is not None else None, float(eps), int(bool(relu)), float(p_drop),
-                                          int(seed) & 0xFFFFFFFFFFFFFFFF, float(momentum),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, L.ptr(seed_dev) if seed_dev is not None else None, float(momentum),
                                           L.ptr(running_mean) if running_mean is not None else None,
                                           L.ptr(running_var) if running_var is not None else None,
                                           L.ptr(y), D, L.ptr(stats), L.stream())
@@ -310,7 +335,7 @@ def bn_relu_dropout(x, gamma, beta, eps, relu, p_drop, seed, momentum=0.0, runni
     return y, stats
 
 
-def bn_relu_dropout_bwd(x, grad_y, stats, gamma, beta, eps, relu, p_drop, seed):
+def bn_relu_dropout_bwd(x, grad_y, stats, gamma, beta, eps, relu, p_drop, seed, seed_dev=None):
     """-> (dL/dx [N,D], gsum fp64 [2*D] = dL/dbeta | dL/dgamma)."""
     N, D = x.shape
     gx = torch.empty(N, D, dtype=torch.float32, device=x.device)
@@ -318,6 +343,7 @@ def bn_relu_dropout_bwd(x, grad_y, stats, gamma, beta, eps, relu, p_drop, seed):
     rc = L.lib().bgnn_bn_relu_dropout_bwd_f32(L.ptr_rows(x), L.ptr_rows(grad_y), N, D, x.stride(0), grad_y.stride(0), L.ptr(stats),
                                               L.ptr(gamma) if gamma is not None else None, L.ptr(beta) if beta is not None else None,
                                               float(eps), int(bool(relu)), float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              L.ptr(seed_dev) if seed_dev is not None else None,
                                               L.ptr(gx), D, L.ptr(gsum), L.stream())
     L.check(rc, "bgnn_bn_relu_dropout_bwd_f32")
     return gx, gsum.view(-1, 2 * D).sum(0)
@@ -399,19 +425,16 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None, tail_s
     return out
 
 
-_TILE_QUEUES = {}
 # second-part launches (a boundary row's two or three remote-source edges) run without the tile queue: nothing to keep
 # L2-resident there, and the claims' latency is most of such a short row's time (0.67 -> 0.64 ms per rank-sized forward)
 _P2_STATIC = os.environ.get("BGNN_P2_STATIC", "1") != "0"
 
 
 def _tile_queue(dev):
-    """8 x uint32 scratch per (device, stream) for the aggregation kernel's per-XCD dynamic tile counters."""
-    key = (torch.device(dev).index, L.raw_stream())
-    q = _TILE_QUEUES.get(key)
-    if q is None:
-        q = _TILE_QUEUES[key] = torch.empty(8, dtype=torch.int32, device=dev)     # the C entry zeroes it on the stream per launch
-    return q
+    """8 x uint32 scratch for the aggregation kernel's per-XCD dynamic tile counters (the C entry zeroes it on the stream per
+    launch, with a kernel of its own -- see bgnn_zero_async in csrc/bgnn_common.h).  A fresh allocation per call: the scratch has
+    no life outside its launch, so nothing created inside a HIP-graph capture has to stay valid between replays."""
+    return torch.empty(8, dtype=torch.int32, device=dev)
 
 
 def heads_log_softmax_supported(heads, D):
@@ -448,6 +471,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
         out = torch.empty(n_dst, heads * ldo, dtype=torch.float32, device=dev)
     assert h_t2s.stride(0) == h_s2t.stride(0) and h_t2s.stride(0) % heads == 0 and out.stride(0) % heads == 0
     alpha = torch.empty(csr.num_edges, dtype=torch.float32, device=dev) if want_alpha else None
+    tq = _tile_queue(dev) if heads == 1 else None            # (alive until the launch below has been issued)
     if row_end <= int(row_begin):                    # empty row range (e.g. no boundary rows at world size 1)
         return (out, alpha) if want_alpha else out
     # graphs with hub rows: segments + merge (bgnn.h).  Whole-graph, single-launch calls of the two hub-aware kernels only.
@@ -465,7 +489,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
                 L.ptr(mask_u8), n_dst, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads,
                 L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0),
                 L.ptr(state_ms) if part == 3 else None, int(heads), L.ptr(colsum),
-                L.ptr(_tile_queue(dev)) if heads == 1 else None, HUB_THRESHOLD, L.ptr(hub_rows), int(hub_rows.numel()),
+                L.ptr(tq), HUB_THRESHOLD, L.ptr(hub_rows), int(hub_rows.numel()),
                 L.ptr(seg_ptr), L.ptr(seg_bounds), L.ptr(seg_node), nseg, L.ptr(alpha), L.ptr(ws), wsb, L.stream())
             L.check(rc, "bgnn_adaptedconv_aggregate_hub_f32")
             return (out, alpha) if want_alpha else out
@@ -474,7 +498,7 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
         L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part),
         int(row_begin) if park_begin is None else int(park_begin), int(heads), L.ptr(colsum),
-        L.ptr(_tile_queue(dev)) if heads == 1 and not (part == 2 and _P2_STATIC) else None, L.stream())
+        L.ptr(tq) if not (part == 2 and _P2_STATIC) else None, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return (out, alpha) if want_alpha else out
 

@@ -123,17 +123,19 @@ int bgnn_gram_f32(const float* A, int64_t lda, int32_t p, const float* B, int64_
  *   of x | x^2, written here and kept for the backward); y = keep(seed, element) ? max(gamma*(x-mean)/sqrt(var+eps)+beta, 0) / (1-p) : 0.
  *   The dropout mask is a counter-based hash of (seed, element index) with 16 bits per element (p is rounded to 1/65536) -- the
  *   same Bernoulli(1-p) law as torch's Philox stream, not the same bits.  running_mean / running_var (both or neither) get torch's
- *   momentum update with the unbiased variance.
+ *   momentum update with the unbiased variance.  `seed_dev_opt` (device, may be NULL): a 64-bit word added to `seed` by the kernels --
+ *   a captured HIP graph bakes the host value of `seed` in, the device word (advanced by the caller once per step) keeps the masks of
+ *   successive replays different; forward and backward of one step must see the same word.
  * bgnn_bn_relu_dropout_bwd_f32: dL/dx from dL/dy; the ReLU state is re-derived from x and the mask from (seed, index); `gsum`
  *   (bgnn_bn_acc_doubles(D) doubles = R x [2*D] partials, written here; summed over R) returns sum g' = dL/dbeta and sum g'.xhat = dL/dgamma (g' = dL/d(BN output)). */
 int64_t bgnn_bn_acc_doubles(int32_t D);   /* size in doubles of `stats` / `gsum` below: R partial accumulators of [2*D]; their sum over R is the total */
 int bgnn_bn_relu_dropout_f32(const float* x, int64_t N, int32_t D, int64_t ldx, const float* gamma_opt,
-                             const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed,
+                             const float* beta_opt, float eps, int relu, float p_drop, uint64_t seed, const uint64_t* seed_dev_opt,
                              float momentum, float* running_mean_opt, float* running_var_opt,
                              float* y, int64_t ldy, double* stats, void* stream);
 int bgnn_bn_relu_dropout_bwd_f32(const float* x, const float* grad_y, int64_t N, int32_t D, int64_t ldx, int64_t ldg,
                                  const double* stats, const float* gamma_opt, const float* beta_opt, float eps,
-                                 int relu, float p_drop, uint64_t seed, float* grad_x, int64_t ldgx,
+                                 int relu, float p_drop, uint64_t seed, const uint64_t* seed_dev_opt, float* grad_x, int64_t ldgx,
                                  double* gsum, void* stream);
 /* bgnn_transform_bwd_prep_f32: row-local part of the transform's hand-derived backward (KTGNN.py:275-284 under autograd) in
  *   one stream over x and the two incoming gradient tables: gate values (tanh of x.gx[g] + gconst[g]), the gates'

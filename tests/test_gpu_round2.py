@@ -353,6 +353,117 @@ def test_c4_full_size_aggregation_backward_vs_torch_autograd():
     assert max(errs["da_t2s"], errs["da_s2t"]) < 1e-4, errs
 
 
+def _small_training_setup(drop):
+    import copy
+    from bridged_gnn_amd import synth, utils
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    x, ei, y, m = synth.sync_rd_intra(n=4000, feat=64, homophily=0.7, deg=8, k_cross=10, seed=2)
+    und = utils.to_undirected(torch.from_numpy(ei).to(DEV), x.shape[0])
+    data = Data(x=torch.from_numpy(x).to(DEV), edge_index=und, central_mask=torch.from_numpy(m).to(DEV))
+    yt = torch.from_numpy(y).to(DEV).clamp_min(0)[:, None]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = torch.rand(x.shape[0], device=DEV, generator=g); w /= w.sum()
+    loss_fn = lambda out: -sum((o.gather(1, yt).squeeze(1) * w).sum() for o in out[:3])
+    torch.manual_seed(0)
+    a = KTGNN_no_complement(64, 2, 2, 64, use_bn=True, dim_share=64, dropout=drop).to(DEV).train()
+    return data, loss_fn, a, copy.deepcopy(a)
+
+
+@pytest.mark.parametrize("opt_name", ["sgd", "adam"])
+def test_graphed_train_step_follows_the_eager_loop(opt_name):
+    """`KTGNN_no_complement.graphed_train_step` (zero_grad + forward + loss + backward + optimizer.step of
+    main_graph_knowledge_transfer.py:39-68 as ONE HIP graph) against the same loop run eagerly on a twin model, the two
+    interleaved step by step (eager work between replays is what exposed hipMemsetAsync nodes replaying a stale pattern):
+    losses agree, parameters agree, and an eager eval forward afterwards sees the trained weights (no stale packed copies)."""
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    data, loss_fn, a, b = _small_training_setup(0.0)
+    mk = (lambda ps: torch.optim.SGD(ps, lr=0.05)) if opt_name == "sgd" else (lambda ps: torch.optim.Adam(ps, lr=1e-3, capturable=True))
+    oa, ob = mk(a.parameters()), mk(b.parameters())
+    W = 2
+    run = a.graphed_train_step(data, loss_fn, oa, warmup=W)
+
+    def eager():
+        ob.zero_grad(set_to_none=True)
+        l = loss_fn(b(data)); l.backward(); ob.step()
+        return float(l.detach())
+    for _ in range(W):
+        eager()
+    for i in range(25):
+        la, lb = float(run().detach()), eager()
+        # SGD: the two runs differ by the order of fp32 atomics only.  Adam normalises every coordinate's step to ~lr, also the ones whose
+        # gradient is rounding noise (exactly-zero gradients before a BatchNorm), so two runs of the SAME loop drift apart slowly
+        tol = 2e-5 if opt_name == "sgd" else (1e-3 if i < 8 else 2e-2)
+        assert abs(la - lb) <= tol * abs(lb), (i, la, lb)
+    if opt_name == "sgd":                      # (Adam turns the rounding noise of the exactly-zero gradients before a BatchNorm into +-lr steps)
+        for (n_, p), q in zip(a.named_parameters(), b.parameters()):
+            assert float((p.detach() - q.detach()).abs().max()) <= 1e-4 * float(q.detach().abs().max()) + 1e-7, n_
+    a.eval()
+    fresh = KTGNN_no_complement(64, 2, 2, 64, use_bn=True, dim_share=64).to(DEV).eval()
+    fresh.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        for u, v in zip(a(data)[:3], fresh(data)[:3]):
+            assert torch.allclose(u, v, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        a.graphed_train_step(data, loss_fn, oa)                    # eval mode
+    a.train()
+    with pytest.raises(RuntimeError):
+        a.graphed_train_step(data, loss_fn, torch.optim.Adam(a.parameters(), lr=1e-3))    # not capturable
+
+
+def test_graphed_train_step_draws_a_new_dropout_mask_per_replay():
+    """the seed baked into the graph + the device step counter advanced inside it: with the weights held still (lr = 0) every
+    replay still sees another dropout mask, i.e. another loss"""
+    data, loss_fn, a, _ = _small_training_setup(0.5)
+    run = a.graphed_train_step(data, loss_fn, torch.optim.SGD(a.parameters(), lr=0.0))
+    losses = [float(run().detach()) for _ in range(6)]
+    assert len(set(losses)) == len(losses), losses
+    assert int(run.step.item()) >= 6
+
+
+def test_graph_replays_survive_eager_work_between_them():
+    """Regression: the aggregation's tile counters used to be cleared with hipMemsetAsync; captured after a warm-up on a side stream,
+    that memset NODE filled them with a stale pattern as soon as eager work had run between two replays, and the replay computed
+    nothing (bgnn_zero_async in csrc/bgnn_common.h is a kernel of our own now)."""
+    from bridged_gnn_amd import ops, synth
+    n, D = 6000, 128
+    ei, mask = synth.random_multigraph(n, 10 * n, frac_src=0.4, n_isolated=2, seed=9)
+    csr = ops.build_dst_csr(_t(ei), n)
+    m8 = _t(mask).to(torch.uint8)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    h1, h2 = torch.randn(n, D, device=DEV, generator=g), torch.randn(n, D, device=DEV, generator=g)
+    a1, a2 = torch.randn(D, device=DEV, generator=g) * 0.1, torch.randn(D, device=DEV, generator=g) * 0.1
+    f = lambda A, B: ops.adaptedconv_aggregate(A, B, a1, a2, csr, m8, D, 0.1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            f(h1, h2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        h1.mul_(0.97); h2.mul_(0.97)
+        res = f(h1, h2)
+    for i in range(5):
+        gr.replay()
+        torch.cuda.synchronize()
+        ref = f(h1.clone(), h2.clone())                            # eager work between the replays (and the expected value)
+        assert torch.equal(res, ref), i
+
+
+def test_total_sum_and_column_sums():
+    from bridged_gnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(70001, device=DEV, generator=g).requires_grad_(True)
+    s = ops.total_sum(x)
+    assert abs(float(s) - float(x.detach().double().sum())) < 1e-3
+    s.backward()
+    assert torch.equal(x.grad, torch.ones_like(x))
+    y = torch.randn(5000, 128, device=DEV, generator=g)
+    assert torch.allclose(ops.column_sums(y), y.double().sum(0).float(), rtol=1e-6, atol=1e-5)
+
+
 def test_input_domain_sums_cache_follows_x():
     """the cached domain sums of the (static) input features are dropped when x is written in place or replaced"""
     from bridged_gnn_amd import synth
