@@ -9,6 +9,8 @@ from oracle import oracle_c as OC
 from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
+TIE_ROWS = {591: 11, 888: 15}   # rows (of Nt) whose top-k SET differs from the reference's torch.topk on the office fixtures: k-boundary ties under
+                                # the declared rule (canonical fp64 score desc, index asc); measured, pinned so that the count cannot drift
 DEV = "cuda:0"
 
 
@@ -120,6 +122,9 @@ def test_office_bridge_from_shipped_ckpt(golden, tag, kc):
     srt = np.sort(s, axis=1)
     same = np.array([set(a) == set(b) for a, b in zip(idx.cpu().numpy(), f["cross_idx"])])
     assert ((srt[:, -kc] - srt[:, -kc - 1])[~same] < 2e-6).all()
+    n_tie_rows = int((~same).sum())
+    print(f"rows whose top-k SET differs from the reference's torch.topk (k-boundary ties under the declared rule): {n_tie_rows} of {same.shape[0]}")
+    assert n_tie_rows == TIE_ROWS[same.shape[0]], n_tie_rows
     assert ei.shape == f["cross_edge_index"].shape
     assert np.array_equal(pcs.argmax(1).cpu().numpy(), f["pred_clf_src"]) and np.array_equal(pct.argmax(1).cpu().numpy(), f["pred_clf_tar"])
     assert_close(pcs.cpu().numpy()[::16], f["probs_clf_src_rows"], what="probs_clf_src")
