@@ -1,3 +1,7 @@
+"""The wide aggregation inside a captured HIP graph whose inputs change per replay, with eager work between replays.
+Variants on the command line: plain | fn | fn+grad | plain+side | fn+grad+side (fn: through the autograd Function, grad: leaves require
+grad, side: warm-up on a side stream).  With hipMemsetAsync clearing the tile counters, every `+side` variant froze from replay 1 on
+(the memset node replayed a stale pattern); with bgnn_zero_async all variants are exact.  GPU box."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bridged_gnn_amd import ops, synth, utils

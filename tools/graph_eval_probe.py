@@ -1,3 +1,4 @@
+"""Replays of the captured eval forward (model.graphed) on configs 2 and 3 against the eager forward, several replays in a row.  GPU box."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bridged_gnn_amd import synth, utils

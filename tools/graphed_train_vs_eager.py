@@ -1,3 +1,5 @@
+"""graphed_train_step vs the same loop run eagerly on a twin model, interleaved step by step (adam | adam_single | adam_fused | sgd_mom |
+adam_eager_twin = eager vs eager as the control); prints the steps where the losses differ by more than 1e-3 and the last one.  GPU box."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
