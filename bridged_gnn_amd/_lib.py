@@ -101,9 +101,28 @@ def _sidecar_hash():
         return None
 
 
+# the ABI revision this binding was written for (include/bgnn.h: BGNN_VERSION); checked against the loaded library
+ABI_VERSION = 110
+
+
 def _make():
+    """Rebuild the library under an exclusive file lock: in a multi-rank launch after a source edit every rank finds the
+    stale sidecar at once, and unserialised `make` runs in one directory corrupt the objects / hand a rank a half-written
+    .so.  The first rank in builds (the Makefile links to a temporary name and renames it into place, sidecar last); the
+    others wait on the lock, re-check the sidecar and find nothing left to do.  A failing build raises with make's output."""
+    import fcntl
     import subprocess
-    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "-s"], check=False)
+    csrc = os.path.join(_HERE, "csrc")
+    with open(os.path.join(csrc, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(SO_PATH) and _sidecar_hash() == source_hash():
+                return                                     # another process built it while this one waited
+            r = subprocess.run(["make", "-C", csrc, "-j4", "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"building {SO_PATH} failed (make exit code {r.returncode}):\n{r.stdout[-4000:]}")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def _load():
@@ -135,6 +154,8 @@ def lib():
             raise RuntimeError(
                 f"{SO_PATH} was built from other sources (library {got}, tree {want}): rebuild it with "
                 "`make -C bridged_gnn_amd/csrc` (a loaded library cannot be replaced inside this process)")
+        if l.bgnn_version() != ABI_VERSION:
+            raise RuntimeError(f"{SO_PATH} exports ABI revision {l.bgnn_version()}, this binding was written for {ABI_VERSION}")
         _lib = l
     return _lib
 

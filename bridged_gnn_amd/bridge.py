@@ -146,18 +146,35 @@ class BridgeScorer:
                      s["biasatt.2.weight"], s["biasatt.2.bias"])
         return (u + b).contiguous()
 
-    def mlp_terms(self, z_cand, z_query):
-        """A[cand], B[query], bn2 scale/shift, w2, b2 (models.py:918-925, :949-951); first half of the
-        concatenation is the idx1 ('from'/candidate) side."""
+    def mlp_consts(self):
+        """bn2 scale / shift, w2, b2 of the mlp scorer (models.py:921-925); constants of the checkpoint, formed once (the
+        bias read-back is the only host sync of the mlp path)."""
+        c = getattr(self, "_mlp_consts", None)
+        if c is None:
+            s = self.sim
+            scale, shift = _bn_affine(s, "lin_self.2.")
+            c = self._mlp_consts = (scale.contiguous(), shift.contiguous(), s["lin_self.4.weight"].reshape(-1).contiguous(),
+                                    float(s["lin_self.4.bias"].reshape(-1)[0].item()))
+        return c
+
+    def mlp_term_cand(self, z_cand):
+        """A[cand]: the idx1 ('from' / candidate) half of the first Linear on the concatenation (models.py:918-920)"""
         s = self.sim
         h = z_cand.shape[1]
         a, c = _bn_affine(s, "lin_self.0.")
-        W1, b1 = s["lin_self.1.weight"], s["lin_self.1.bias"]
-        A = F.linear(z_cand * a[:h] + c[:h], W1[:, :h])
-        B = F.linear(z_query * a[h:] + c[h:], W1[:, h:], b1)
-        scale, shift = _bn_affine(s, "lin_self.2.")
-        return (A.contiguous(), B.contiguous(), scale.contiguous(), shift.contiguous(),
-                s["lin_self.4.weight"].reshape(-1).contiguous(), float(s["lin_self.4.bias"].reshape(-1)[0].item()))
+        return F.linear(z_cand * a[:h] + c[:h], s["lin_self.1.weight"][:, :h]).contiguous()
+
+    def mlp_term_query(self, z_query):
+        """B[query]: the idx2 half, carrying the Linear's bias"""
+        s = self.sim
+        h = z_query.shape[1]
+        a, c = _bn_affine(s, "lin_self.0.")
+        return F.linear(z_query * a[h:] + c[h:], s["lin_self.1.weight"][:, h:], s["lin_self.1.bias"]).contiguous()
+
+    def mlp_terms(self, z_cand, z_query):
+        """A[cand], B[query], bn2 scale/shift, w2, b2 (models.py:918-925, :949-951); first half of the
+        concatenation is the idx1 ('from'/candidate) side."""
+        return (self.mlp_term_cand(z_cand), self.mlp_term_query(z_query)) + self.mlp_consts()
 
     def topk(self, z_cand, z_query, k, rank=0, world=1, group=None):
         """-> (idx [Nq,k] int64, probs [Nq,k] fp32, n_fallback) ; rows sorted by (score desc, idx asc).
@@ -170,8 +187,8 @@ class BridgeScorer:
         qlo, qhi = shard_range(z_query.shape[0], rank, world)
         zc, zq = z_cand[clo:chi], z_query[qlo:qhi]
         if self.sim_mode == "mlp":
-            A, _, scale, shift, w2, b2 = self.mlp_terms(zc, zq[:0])
-            _, B, _, _, _, _ = self.mlp_terms(zc[:0], zq)
+            A, B = self.mlp_term_cand(zc), self.mlp_term_query(zq)
+            scale, shift, w2, b2 = self.mlp_consts()
             A = all_gather_rows(A, group, world)
             return ops.mlp_pair_topk(A.contiguous(), B, scale, shift, w2, b2, k, apply_sigmoid=True)
         qc_local = ops.l2_normalize_rows(self.cosine_q(zc))

@@ -42,7 +42,15 @@ def all_gather_rows(t, group=None, world=None, always=False):
     one tiny all_gather of the heights + ONE all_gather of the padded payload (RCCL: direct full mesh over xGMI, every
     peer pair its own link).  The kNN bridge's only collective (`all_gather` of q_cand).  A gloo group
     with CUDA tensors (several ranks rehearsing on one GPU) stages the payload through the host."""
-    if not dist.is_initialized() or ((world if world is not None else dist.get_world_size(group)) == 1 and not always):
+    if not dist.is_initialized():
+        if (world is not None and world > 1) or always:
+            # a shard of the candidates would otherwise be scored as if it were the whole set -- silently wrong edges
+            raise RuntimeError(f"all_gather_rows(world={world}, always={always}) needs an initialised torch.distributed "
+                               "process group")
+        return t
+    if world is not None and world != dist.get_world_size(group):
+        raise RuntimeError(f"all_gather_rows: world={world} but the process group has {dist.get_world_size(group)} ranks")
+    if dist.get_world_size(group) == 1 and not always:
         return t            # `always`: issue the collectives even at world size 1 (smoke-tests the RCCL calls)
     world = dist.get_world_size(group)
     host = t.is_cuda and dist.get_backend(group) == "gloo"
@@ -344,6 +352,13 @@ class PartitionedKTGNN:
             self._x_ext = torch.cat((xp, halo.index_select(0, self.halo_ext_perm)))      # halo regrouped by table
             self._x_ext_key = (weakref.ref(x), x._version)
         return self._x_ext
+
+    def invalidate_input_cache(self):
+        """forget the cached input halo rows and the all-reduced domain sums of `x` (both keyed by tensor identity +
+        `_version`): call it after a write to x that does not advance the version (`x.data[...] = ...`, an alias, a
+        raw-pointer kernel) -- same contract as `KTGNN_no_complement.invalidate_input_cache`."""
+        self._x_sums_key, self._x_sums = None, None
+        self._x_ext_key = None
 
     def _conv_resident_halo(self, conv, x, epilogue=None, out_sums=None, arena=None):
         """First conv with resident input halo: all-reduce of the domain sums, transform of local + halo rows, ONE

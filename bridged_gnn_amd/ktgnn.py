@@ -161,6 +161,12 @@ class _BnReluDropFn(torch.autograd.Function):
                                        bias.detach() if bias is not None else None, bn.eps, relu, p_drop, seed, mom,
                                        bn.running_mean if track else None, bn.running_var if track else None,
                                        seed_dev=_DROPOUT_STEP[0])
+        if track:
+            # the kernel wrote running_mean / running_var through raw pointers: their `_version` did not move, so the
+            # caches keyed by it (bn_eval_affine, KTGNN_no_complement._fold_transformer) would go stale with frozen affine
+            # parameters -- bump the versions the way an in-place torch op would
+            torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
+            bn._bgnn_affine = None
         ctx.save_for_backward(x, weight, bias, stats)
         ctx.cfg = (bn.eps, relu, p_drop, seed)
         ctx.seed_dev = _DROPOUT_STEP[0]
@@ -655,7 +661,8 @@ class KTGNN_no_complement(nn.Module):
         like the graph (the reference runs 300 epochs x 3 forwards on one `data.x`), so the sums are cached against the
         tensor objects and their in-place versions: an unchanged x is not streamed again (0.11 ms of a 2.2 ms forward on
         C4); a new tensor or an in-place write recomputes them."""
-        if torch.cuda.is_current_stream_capturing():          # a captured forward must re-read x on every replay
+        if torch.cuda.is_current_stream_capturing() or not getattr(self, "cache_input_sums", True):
+            # a captured forward must re-read x on every replay; `cache_input_sums = False`: the reference's behaviour
             return ops.domain_sums(x, _as_u8(central_mask).contiguous(), out=arena.take(2 * x.shape[1] + 2))
         c = getattr(self, "_xsum_cache", None)
         if (c is not None and c[0]() is x and c[1] == x._version and c[2]() is central_mask and c[3] == central_mask._version):
@@ -849,6 +856,15 @@ class KTGNN_no_complement(nn.Module):
         self._tf_key = None
         self._tf_pack = None
         self._a3_key = None
+        for bn in list(self.bns) + [self.clf_transformer[1]]:      # eval-mode scale / shift (bn_eval_affine)
+            bn._bgnn_affine = None
+
+    def invalidate_input_cache(self):
+        """forget the memoised per-domain sums of `data.x` (`_input_domain_sums`).  The cache is keyed by tensor identity and
+        `_version`; a write that does not advance the version (`x.data[...] = ...`, a DLPack / numpy alias, a raw-pointer kernel
+        writing through `out=`) must be followed by this call -- the reference recomputes the means on every forward
+        (KTGNN.py:275).  `cache_input_sums = False` on the model switches the memo off altogether."""
+        self._xsum_cache = None
 
     def graphed_train_step(self, data, loss_fn, optimizer, warmup=3):
         """One training step of the reference's loop (main_graph_knowledge_transfer.py:39-68: zero_grad, forward, loss,

@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
-#define BGNN_VERSION 100
+/* ABI revision.  110 (round 3) is NOT call-compatible with 100: `bgnn_transform_bwd_prep_f32` takes 22 arguments (was 17)
+ * and the `n_fallback_opt` of `bgnn_cosine_topk_f32` / `bgnn_mlp_pair_topk_f32` is int32[2] (was int32[1]) -- a caller built
+ * against the old header must be recompiled; compare bgnn_version() with the BGNN_VERSION it was built with at load time. */
+#define BGNN_VERSION 110
 #define BGNN_E_NULL (-1)        /* required pointer is NULL                     */
 #define BGNN_E_SHAPE (-2)       /* unsupported / inconsistent shape             */
 #define BGNN_E_WORKSPACE (-3)   /* ws_bytes smaller than *_workspace_bytes()    */

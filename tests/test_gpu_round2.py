@@ -411,6 +411,54 @@ def test_graphed_train_step_follows_the_eager_loop(opt_name):
         a.graphed_train_step(data, loss_fn, torch.optim.Adam(a.parameters(), lr=1e-3))    # not capturable
 
 
+def test_eval_passes_between_graph_replays_see_fresh_batchnorm_state():
+    """Regression (round-2 advisor, high): `bn_eval_affine` caches BatchNorm(eval) scale / shift per host-side version
+    counters, which a replayed HIP graph never advances -- from the SECOND eval pass on the hidden BN used the parameters
+    and running statistics frozen at the first one.  Interleave eval forwards with replays (the workflow of
+    tools/train_300_epochs.py) and compare every one of them with a fresh model loaded from the state_dict."""
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    data, loss_fn, a, _ = _small_training_setup(0.5)
+    run = a.graphed_train_step(data, loss_fn, torch.optim.SGD(a.parameters(), lr=0.05), warmup=2)
+    prev = None
+    for rnd in range(4):
+        for _ in range(3):
+            run()
+        a.eval()
+        fresh = KTGNN_no_complement(64, 2, 2, 64, use_bn=True, dim_share=64).to(DEV).eval()
+        fresh.load_state_dict(a.state_dict())
+        with torch.no_grad():
+            got, want = [o.clone() for o in a(data)[:3]], fresh(data)[:3]
+        for u, v in zip(got, want):
+            assert torch.allclose(u, v, rtol=1e-6, atol=1e-6), rnd
+        if prev is not None:                                      # the weights did move between the eval passes
+            assert not torch.allclose(prev[0], got[0], rtol=1e-4, atol=1e-5)
+        prev = got
+        a.train()
+
+
+def test_eager_training_with_frozen_bn_affine_keeps_eval_caches_fresh():
+    """Regression (same finding): the fused BN+ReLU+dropout kernel writes running_mean / running_var through raw pointers, so
+    with the BN affine parameters frozen nothing used to advance a version counter and the eval-mode caches
+    (`bn_eval_affine`, `_fold_transformer`) kept the statistics of the first eval pass."""
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    data, loss_fn, a, _ = _small_training_setup(0.0)
+    for bn in list(a.bns) + [a.clf_transformer[1]]:
+        bn.weight.requires_grad_(False); bn.bias.requires_grad_(False)
+    opt = torch.optim.SGD([p for p in a.parameters() if p.requires_grad], lr=0.0)    # lr 0: ONLY the running statistics move
+    for rnd in range(3):
+        a.eval()
+        fresh = KTGNN_no_complement(64, 2, 2, 64, use_bn=True, dim_share=64).to(DEV).eval()
+        fresh.load_state_dict(a.state_dict())
+        with torch.no_grad():
+            for u, v in zip(a(data)[:3], fresh(data)[:3]):
+                assert torch.allclose(u, v, rtol=1e-6, atol=1e-6), rnd
+        a.train()
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss_fn(a(data)).backward()
+            opt.step()
+
+
 def test_graphed_train_step_draws_a_new_dropout_mask_per_replay():
     """the seed baked into the graph + the device step counter advanced inside it: with the weights held still (lr = 0) every
     replay still sees another dropout mask, i.e. another loss"""
