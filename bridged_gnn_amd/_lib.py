@@ -89,8 +89,8 @@ def source_hash():
 
 
 # keep in step with HASHED in csrc/Makefile
-_HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
-                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", os.path.join("..", "..", "include", "bgnn.h"))
+_HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_transform_stream.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
+                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", "bgnn_transform_params.h", os.path.join("..", "..", "include", "bgnn.h"))
 
 
 def _sidecar_hash():

@@ -16,6 +16,12 @@
 #include <cstdlib>
 #include <type_traits>
 #include "bgnn_common.h"
+#include "bgnn_transform_params.h"
+
+using bgnn_tf::GemmParams;
+using bgnn_tf::MAXH;
+using bgnn_tf::f32x16;
+using bgnn_tf::tanh_fast;
 
 namespace {
 
@@ -150,36 +156,9 @@ __global__ __launch_bounds__(256) void wd_kernel(const float* __restrict__ Wp, i
 }
 
 // ------------------------------------------------------------------ fused MFMA fp32 GEMM
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BK = 32, LDS_LD = BK + 4;   // +4 floats: conflict-free ds_read_b128 (16-lane groups)
-constexpr int MAXH = 2;
-
-struct GemmParams {
-  const float* x; int64_t ldx; int64_t N; int32_t Din;
-  const uint8_t* mask;
-  const float* Wp;      // [NC, Din] packed: per head, ldh rows of W_t (zero padded) then ldh rows of W_s
-  const float* bias;    // [NC]
-  const float* wd;      // [NC]   Wp . delta
-  const float* g;       // [n_heads][2][2*Din]  gate vectors (s2t, t2s), x-half first
-  const float* gc;      // [n_heads][2]         delta-half constants
-  float* out[MAXH][2];  // [head][table]  table 0 = h_s2t (W_t), 1 = h_t2s (W_s)
-  int64_t ldh; int64_t row_stride; int32_t NC; int32_t n_heads;   // ldh = padded width of a head's row, row_stride >= ldh
-  int32_t relu;         // plain-linear mode (transform_wreg_kernel<.., MODE = 1>): out = relu?(x W^T + b)
-  double* colsum;       // plain-linear mode, optional [2*NC + 2]: per-domain column sums (+ node counts) of the output
-  int32_t col_off;      // transform_wreg_kernel: the launch covers the packed columns [col_off, NC) (one table of a head)
-  // MODE 2 (linear -> narrow transform, the activation never reaches HBM): second-stage operand and raw output
-  const float* w2;      // [8][NC]: packed rows of the consumer conv (4 of W_t, 4 of W_s), zero padded
-  const float* g2;      // [2][2*NC]: its gate vectors (s2t, t2s), x-half first
-  float* raw;           // [N][12]: W_t.a (4) | W_s.a (4) | a.g_s2t | a.g_t2s | 0 | 0   for the activation row a
-  // MODE 0, one head: rows [tail_t2s_begin, tail_s2t_begin) need table 1 (h_t2s) only, rows [tail_s2t_begin, N) table 0 only (the
-  // resident input halo of a partitioned graph: a halo row feeds destinations of one domain).  The waves of the other
-  // table sit a whole tile of such rows out (no MFMAs, no stores): half the matrix work and half the writes for them in the
-  // SAME launch (three launches -- both / t2s-only / s2t-only -- measured slower than doing both tables everywhere).
-  // Both = N: no tail.
-  int64_t tail_t2s_begin, tail_s2t_begin;
-};
 
 // BN output columns per block; waves arranged WM x WN, each computing TM x TN tiles of 32x32
 template <int BN, int WM, int WN, int TM, int TN>
@@ -362,8 +341,6 @@ __global__ __launch_bounds__(256) void transform_gemm_kernel(GemmParams p) {
 // fly during the MFMA phase, and with x as the B operand a lane ends up holding 4 CONSECUTIVE output columns of one row,
 // so results leave as 16-byte stores straight from the accumulators (no C staging pass).
 //   DK  : Din rounded up to 64/128 (zero-filled),  NCT : 32-column tiles per block (2/4/8); 8/NCT row sub-tiles.
-// tanh through v_exp_f32 + v_rcp_f32 (abs. error < 5e-7; the coefficient scales an O(1) rank-1 term)
-__device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f); }
 
 
 template <int DK, int NCT, int NW, bool BF3, int MODE>
@@ -995,6 +972,9 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
     p.tail_s2t_begin = N - n_tail_s2t;
     if (p.tail_s2t_begin == 0) p.tail_s2t_begin = 1, p.tail_t2s_begin = p.tail_t2s_begin > 1 ? 1 : p.tail_t2s_begin;   // (rows from 0: keep the "tails on" encoding; a tile never ends at row 0)
   }
+  // barrier-free producer / consumer pipeline (bgnn_transform_stream.hip): one head, 128 or 256 packed columns, 64 < Din <= 128
+  static const bool use_stream = [] { const char* e = getenv("BGNN_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+  if (use_stream && bgnn_tf_stream_supported(p, 0)) return bgnn_tf_stream_launch(p, 0, st, n_cu);
   if (use_wreg && NC % 64 == 0 && Din <= 128) {   // (Din = 256 needs 128 weight registers per lane and spills)
     // W-stationary persistent kernel: one 512-thread block per CU, column groups of 32*NCT in grid.y
     // NC <= 64: 4-wave blocks (2 column tiles x 2 row sub-tiles), two per CU; wider: 8-wave blocks, one per CU
