@@ -397,6 +397,8 @@ def check_added_edges_within_domain_validity(edge_index_added, e_sim, data_in, p
 def _as_index(mapper, n):
     """orig-id -> local-index mapping given as a dict (reference `dataset_conversion`, utils.py:58-63) or as a
     LongTensor of the original ids in local order; returns the LongTensor form."""
+    if hasattr(mapper, "orig"):                      # IndexMapper of this package's dataset_conversion
+        return mapper.orig
     if isinstance(mapper, dict):
         out = torch.empty(n, dtype=torch.int64)
         for orig, loc in mapper.items():
@@ -420,6 +422,71 @@ def reorder(data_merge, data_src, mapper_idx_src, mapper_idx_tar):
             setattr(data_merge, key, getattr(data_merge, key)[merged_of_orig])
     data_merge.edge_index = orig_of_merged[data_merge.edge_index]                 # :221
     return data_merge
+
+
+def _dataset_split(data, num_classes, ratio):
+    """utils.py:20-38.  The permutations come from torch's global CPU generator in the reference's call order (one `randperm` per
+    class), so a `set_random_seed(seed)` in front reproduces its split bit for bit; everything else is index arithmetic."""
+    import numpy as np
+    y_cpu = data.y.cpu()
+    for c in range(num_classes):
+        idx = (y_cpu == c).nonzero(as_tuple=False).view(-1)
+        nc = idx.shape[0]
+        n_train = int(np.ceil(nc * ratio[0]))
+        n_val = int(np.floor(nc * ratio[1]))
+        assert nc - n_train - n_val >= 0
+        perm = torch.randperm(nc)
+        dev = data.train_mask.device
+        data.train_mask[idx[perm[:n_train]].to(dev)] = True
+        data.val_mask[idx[perm[n_train:n_train + n_val]].to(dev)] = True
+        data.test_mask[idx[perm[n_train + n_val:]].to(dev)] = True
+
+
+class IndexMapper(dict):
+    """orig-id -> local-index mapping of `dataset_conversion` (the reference returns a Python dict built in a per-node loop,
+    utils.py:58-63).  Still a dict for the reference's call sites (`reorder`, main_bridged_graph.py:199-203), built from and
+    carrying the LongTensor `orig` of original ids in local order, which this package's vectorised `reorder` uses directly."""
+
+    def __init__(self, orig):
+        orig = torch.as_tensor(orig, dtype=torch.int64).cpu()
+        super().__init__(zip(orig.tolist(), range(orig.shape[0])))
+        self.orig = orig
+
+
+def dataset_conversion(data, seed=0, train_val_test_ratio=(0.6, 0.2, 0.2), dataset_name=None, split_data=True):
+    """utils.py:41-99: cut a VS-graph into its source (`central_mask`) and target component with local node ids, labels and
+    fresh train / val / test masks -> (data_src, data_tar, mapper_idx_src, mapper_idx_tar).  Same results as the reference
+    (fixture `tests/golden/f4_utils.npz`, both split modes) without its per-node / per-edge Python loops: the id maps are one
+    `cumsum`, the edge relabelling one gather.  Works on the device `data` lives on; the class permutations are drawn from
+    torch's CPU generator in the reference's order."""
+    from .data import Data
+    from .utils import set_random_seed
+    set_random_seed(seed)
+    cm = data.central_mask.bool()
+    dev = cm.device
+    x_src, x_tar = data.x[cm], data.x[~cm]
+    if dataset_name in ("company", "twitter"):                                   # :45-49
+        x_tar = x_tar[:, :33 if dataset_name == "company" else 300]
+    idx_src, idx_tar = torch.where(cm)[0], torch.where(~cm)[0]
+    local = torch.where(cm, torch.cumsum(cm.long(), 0) - 1, torch.cumsum((~cm).long(), 0) - 1)   # id inside the node's own domain
+    ei = data.edge_index
+    s_src, s_dst = cm[ei[0]], cm[ei[1]]
+    ei_src = local[ei[:, s_src & s_dst]]                                          # :66,:68 (edge order kept)
+    ei_tar = local[ei[:, ~s_src & ~s_dst]]
+
+    def blank(n):
+        return torch.zeros(n, dtype=torch.bool, device=dev)
+    ns, nt = idx_src.shape[0], idx_tar.shape[0]
+    data_src = Data(x=x_src, edge_index=ei_src, y=data.y[cm], train_mask=blank(ns), val_mask=blank(ns), test_mask=blank(ns))
+    data_tar = Data(x=x_tar, edge_index=ei_tar, y=data.y[~cm], train_mask=blank(nt), val_mask=blank(nt), test_mask=blank(nt))
+    num_classes = int(data.y.max().item()) + 1
+    _dataset_split(data_src, num_classes, train_val_test_ratio)                   # :81
+    if split_data:
+        _dataset_split(data_tar, num_classes, train_val_test_ratio)               # :83
+    else:                                                                         # :85-95: keep the data's own split
+        for key in ("train_mask", "val_mask", "test_mask"):
+            setattr(data_tar, key, getattr(data, key).bool()[~cm].clone())
+    return data_src, data_tar, IndexMapper(idx_src), IndexMapper(idx_tar)
 
 
 def eval_bridged_Graph(data_merge, verbose=False):

@@ -6,7 +6,16 @@ import torch
 
 from . import ops
 
-__all__ = ["remove_self_loops", "add_self_loops", "coalesce", "to_undirected", "set_random_seed"]
+__all__ = ["remove_self_loops", "add_self_loops", "coalesce", "to_undirected", "set_random_seed", "dataset_conversion",
+           "eval_bridged_Graph", "eval_homophily"]
+
+
+def __getattr__(name):
+    # the reference keeps these three in utils.py (:41-131); they live with the graph-assembly code in bridge.py
+    if name in ("dataset_conversion", "eval_bridged_Graph", "eval_homophily"):
+        from . import bridge
+        return getattr(bridge, name)
+    raise AttributeError(name)
 
 
 def _need_cuda(t):

@@ -193,14 +193,74 @@ def round2_sections(KT, MD, BG, want):
         save("assembly_office_a2d.npz", **arrs)
 
 
+def round3_sections(want):
+    """Round 3 (`--only f4`): SURVEY 8(f) rank 4 leftovers -- the reference's `utils.dataset_conversion` (:41-99, both split modes),
+    `eval_bridged_Graph` (:101-113) and `eval_homophily` (:115-131; it only PRINTS its two ratios: they are parsed from stdout) run
+    on a seeded synthetic VS-graph under the shim (oracle/shim/torch_sparse: SparseTensor / matmul restated)."""
+    if not want("f4"):
+        return
+    import contextlib
+    import io
+    import utils as RU                       # the reference's utils.py (sys.path set by ref_import)
+    from torch_geometric.data import Data as SData
+    print("[f4] dataset_conversion / eval_bridged_Graph / eval_homophily")
+    rng = np.random.default_rng(2024)
+    n, F_, C = 700, 12, 3
+    cm = rng.random(n) < 0.45
+    x = rng.standard_normal((n, F_)).astype(np.float32)
+    y = rng.integers(-1, C, n).astype(np.int64)                    # -1 = unlabeled
+    ei = rng.integers(0, n, (2, 4200)).astype(np.int64)            # within- and cross-domain edges, duplicates, self loops
+    tr = rng.random(n) < 0.5
+    va = ~tr & (rng.random(n) < 0.5)
+    te = ~tr & ~va
+
+    def mk():
+        return SData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei), y=torch.from_numpy(y),
+                     central_mask=torch.from_numpy(cm), train_mask=torch.from_numpy(tr), val_mask=torch.from_numpy(va),
+                     test_mask=torch.from_numpy(te))
+    arrs = dict(x=x, y=y.astype(np.int16), edge_index=ei.astype(np.int32), central_mask=cm, train_mask=tr, val_mask=va, test_mask=te)
+    for tag, split in (("split", True), ("keep", False)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds, dt, ms, mt = RU.dataset_conversion(mk(), seed=3, train_val_test_ratio=[0.6, 0.2, 0.2], dataset_name=None, split_data=split)
+        inv_s = np.empty(len(ms), dtype=np.int32); inv_t = np.empty(len(mt), dtype=np.int32)
+        for o, l in ms.items(): inv_s[l] = o
+        for o, l in mt.items(): inv_t[l] = o
+        for nm, d in (("src", ds), ("tar", dt)):
+            arrs.update({f"{tag}_{nm}_x": d.x.numpy(), f"{tag}_{nm}_edge_index": d.edge_index.numpy().astype(np.int32),
+                         f"{tag}_{nm}_y": d.y.numpy().astype(np.int16), f"{tag}_{nm}_train": d.train_mask.numpy(),
+                         f"{tag}_{nm}_val": d.val_mask.numpy(), f"{tag}_{nm}_test": d.test_mask.numpy()})
+        arrs.update({f"{tag}_orig_of_src": inv_s, f"{tag}_orig_of_tar": inv_t})
+    # the 'twitter' branch (:45-49): target features cut to the first 300 columns
+    xw = rng.standard_normal((60, 310)).astype(np.float32)
+    cw = rng.random(60) < 0.5
+    dw = SData(x=torch.from_numpy(xw), edge_index=torch.from_numpy(rng.integers(0, 60, (2, 200)).astype(np.int64)),
+               y=torch.from_numpy(rng.integers(0, 2, 60).astype(np.int64)), central_mask=torch.from_numpy(cw),
+               train_mask=torch.zeros(60, dtype=torch.bool), val_mask=torch.zeros(60, dtype=torch.bool), test_mask=torch.zeros(60, dtype=torch.bool))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds, dt, _, _ = RU.dataset_conversion(dw, seed=1, dataset_name="twitter")
+    arrs.update(tw_x=xw, tw_central=cw, tw_src_shape=np.array(ds.x.shape), tw_tar_shape=np.array(dt.x.shape))
+    # evaluation helpers on the whole synthetic graph
+    g = mk()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ratio = RU.eval_bridged_Graph(g)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        RU.eval_homophily(g)
+    vals = [float(l.split(":")[1]) for l in buf.getvalue().splitlines() if ":" in l]
+    arrs.update(eval_bridged_ratio=np.float64(float(ratio)), homophily_1st=np.float64(vals[0]), homophily_2nd=np.float64(vals[1]))
+    print(f"  eval_bridged_Graph {float(ratio):.6f}, homophily {vals[0]:.6f} / 2nd order {vals[1]:.6f}")
+    save("f4_utils.npz", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list of round-2 sections (c3,layers,a4,assembly); default: everything")
+    ap.add_argument("--only", default="", help="comma list of round-2 / round-3 sections (c3,layers,a4,assembly,f4); default: everything")
     only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     KT, MD, BG = ref_import.import_reference()
     if only:
         round2_sections(KT, MD, BG, lambda t: t in only)
+        round3_sections(lambda t: t in only)
         print("done")
         return
     import torch_geometric
@@ -422,6 +482,7 @@ def main():
     save("knn_gauss.npz", ns=np.int64(ns), nt=np.int64(nt), d=np.int64(dimq), k=np.int64(k),
          seed_src=np.int64(21), seed_tar=np.int64(22), e_sim=vals.numpy(), idx=idxs.numpy().astype(np.int32))
     round2_sections(KT, MD, BG, lambda t: True)
+    round3_sections(lambda t: True)
     print("done")
 
 

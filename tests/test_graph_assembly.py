@@ -85,3 +85,42 @@ def test_gen_bridged_graph_pipeline_on_office_embeddings(tmp_path):
     with torch.no_grad():
         lb, lt, lth, _ = net(data)
     assert lb.shape == (n, 31) and torch.isfinite(lb).all() and torch.isfinite(lth).all()
+
+
+def test_dataset_conversion_and_eval_helpers_vs_reference_fixture(golden):
+    """`utils.dataset_conversion` (utils.py:41-99, random and kept splits, the 'twitter' column cut),
+    `eval_bridged_Graph` (:101-113) and `eval_homophily` (:115-131) against outputs of the reference itself
+    (tests/golden/f4_utils.npz, written by oracle/gen_golden.py --only f4 under the torch_sparse shim).  Pure index work: runs
+    on CPU tensors here and on the GPU in the graph-assembly pipeline."""
+    import numpy as np
+    import torch
+    from bridged_gnn_amd import utils as U
+    from bridged_gnn_amd.bridge import dataset_conversion, eval_bridged_Graph, eval_homophily
+    from bridged_gnn_amd.data import Data
+    g = golden("f4_utils.npz")
+    t = torch.from_numpy
+
+    def mk():
+        return Data(x=t(g["x"]), edge_index=t(g["edge_index"].astype(np.int64)), y=t(g["y"].astype(np.int64)),
+                    central_mask=t(g["central_mask"]), train_mask=t(g["train_mask"]), val_mask=t(g["val_mask"]), test_mask=t(g["test_mask"]))
+    assert U.dataset_conversion is dataset_conversion
+    for tag, split in (("split", True), ("keep", False)):
+        ds, dt, ms, mt = dataset_conversion(mk(), seed=3, train_val_test_ratio=[0.6, 0.2, 0.2], dataset_name=None, split_data=split)
+        for nm, d in (("src", ds), ("tar", dt)):
+            assert np.array_equal(d.x.numpy(), g[f"{tag}_{nm}_x"])
+            assert np.array_equal(d.edge_index.numpy(), g[f"{tag}_{nm}_edge_index"].astype(np.int64))
+            assert np.array_equal(d.y.numpy(), g[f"{tag}_{nm}_y"].astype(np.int64))
+            for k in ("train", "val", "test"):
+                assert np.array_equal(getattr(d, k + "_mask").numpy(), g[f"{tag}_{nm}_{k}"]), (tag, nm, k)
+        assert np.array_equal(ms.orig.numpy(), g[f"{tag}_orig_of_src"]) and np.array_equal(mt.orig.numpy(), g[f"{tag}_orig_of_tar"])
+        o0 = int(g[f"{tag}_orig_of_src"][5])
+        assert ms[o0] == 5 and len(ms) == int(g["central_mask"].sum())            # still the reference's dict
+    dw = Data(x=t(g["tw_x"]), edge_index=torch.zeros(2, 0, dtype=torch.int64), y=torch.zeros(60, dtype=torch.int64),
+              central_mask=t(g["tw_central"]), train_mask=torch.zeros(60, dtype=torch.bool), val_mask=torch.zeros(60, dtype=torch.bool),
+              test_mask=torch.zeros(60, dtype=torch.bool))
+    ds, dt, _, _ = dataset_conversion(dw, seed=1, dataset_name="twitter")
+    assert tuple(ds.x.shape) == tuple(g["tw_src_shape"]) and tuple(dt.x.shape) == tuple(g["tw_tar_shape"])
+    d = mk()
+    assert abs(float(eval_bridged_Graph(d)) - float(g["eval_bridged_ratio"])) < 1e-7
+    r1, r2 = eval_homophily(d, second_order=True)
+    assert abs(float(r1) - float(g["homophily_1st"])) < 1e-7 and abs(float(r2) - float(g["homophily_2nd"])) < 1e-7
