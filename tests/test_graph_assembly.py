@@ -41,6 +41,9 @@ def test_eval_diagnostics_small_example():
     assert float(eval_bridged_Graph(d)) == 0.0     # node 5: in-neighbours 0 (same) and 2 (other): 0.5 is not > 0.5
 
 
+STRAY_CROSS_EDGES = 12      # = the 12 swapped-in candidates of the 11 tie rows of the A->D top-k (tests/test_gpu_knn.py: CROSS_EDGE_DIFF)
+
+
 @pytest.mark.gpu
 def test_gen_bridged_graph_pipeline_on_office_embeddings(tmp_path):
     from bridged_gnn_amd import load_bridged_graph
@@ -72,7 +75,9 @@ def test_gen_bridged_graph_pipeline_on_office_embeddings(tmp_path):
     # surviving cross edges are a subset of the unfiltered top-k edges
     full = set(map(tuple, f["cross_edge_index"].T + np.array([0, ns])))
     # (the GPU's declared tie rule differs from the reference's torch.topk on the ~13 exact-tie rows of this graph)
-    assert len(set(map(tuple, cross.T)) - full) <= 40
+    stray = set(map(tuple, cross.T)) - full
+    print(f"surviving cross edges outside the reference's unfiltered top-k list: {len(stray)}")
+    assert len(stray) == STRAY_CROSS_EDGES, len(stray)      # measured; each is a swapped-in candidate of a tie row (test_gpu_knn.py)
     assert 0.0 <= float(eval_bridged_Graph(merged)) <= 1.0
     back = load_bridged_graph(path)
     assert torch.equal(back.edge_index, merged.edge_index.cpu()) and torch.equal(back.central_mask, merged.central_mask.cpu())
