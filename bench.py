@@ -467,11 +467,24 @@ def time_forward(runner, steps, warmup, barrier, timer):
         for _ in range(max(warmup, 1)):
             out = runner()
         barrier()
-        t0 = time.perf_counter()
+        # rehearsal of the timed loop's own pattern (`steps` forwards enqueued back to back, then one sync): the first such burst
+        # of a process makes the HIP runtime block the host once for 40-90 ms (seen at the 2nd iteration, 3 runs of 4, whatever the
+        # kernels are) -- a one-time cost of the runtime, not of the path; untimed like the warm-up
         for _ in range(steps):
             out = runner()
         barrier()
+        host, mem = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = runner()
+            host.append(time.perf_counter())
+            if os.environ.get("BENCH_TRACE"):
+                mem.append((torch.cuda.memory_allocated() >> 20, torch.cuda.memory_reserved() >> 20))
+        barrier()
         dt = time.perf_counter() - t0
+        if os.environ.get("BENCH_TRACE"):
+            print("host ms per iteration of the bracketed loop:", [round((b - a) * 1e3, 2) for a, b in zip([t0] + host[:-1], host)],
+                  "final sync", round((t0 + dt - host[-1]) * 1e3, 2), "MiB allocated/reserved", mem, "allocator", {k: v for k, v in torch.cuda.memory_stats().items() if k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}, file=sys.stderr)
         n2 = max(steps, 20)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
         for a, b in evs:

@@ -28,6 +28,8 @@ SIGNATURES = {
                                                _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "bgnn_adaptedconv_transform_sums_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
                                                     _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "bgnn_adaptedconv_transform_need_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
+                                                    _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "bgnn_linear_narrow_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _P, _P, _P]),
     "bgnn_narrow_transform_finish_f32": (_INT, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
@@ -102,7 +104,7 @@ def _sidecar_hash():
 
 
 # the ABI revision this binding was written for (include/bgnn.h: BGNN_VERSION); checked against the loaded library
-ABI_VERSION = 110
+ABI_VERSION = 111
 
 
 def _make():

@@ -937,7 +937,7 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
                           const float* gates, const float* gate_const_opt,
                           float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                           int64_t ldh, int64_t row_stride, float* small_ws, void* stream,
-                          int64_t n_tail_t2s = 0, int64_t n_tail_s2t = 0) {
+                          int64_t n_tail_t2s = 0, int64_t n_tail_s2t = 0, const int32_t* tile_need = nullptr) {
   if (n_tail_t2s < 0 || n_tail_s2t < 0 || n_tail_t2s + n_tail_s2t > N) return BGNN_E_SHAPE;
   if (!x || !mask || (!delta && !sums) || !Wp || !bias_p || !gates || !h_s2t_0 || !h_t2s_0 || !small_ws) return BGNN_E_NULL;
   if (n_heads < 1 || n_heads > MAXH || (n_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
@@ -974,6 +974,7 @@ static int transform_impl(const float* x, int64_t N, int32_t Din, int64_t ldx,
   }
   // barrier-free producer / consumer pipeline (bgnn_transform_stream.hip): one head, 128 or 256 packed columns, 64 < Din <= 128
   static const bool use_stream = [] { const char* e = getenv("BGNN_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+  p.tile_need = tile_need;                       // (honoured by the stream kernel only; the others write both tables everywhere)
   if (use_stream && bgnn_tf_stream_supported(p, 0)) return bgnn_tf_stream_launch(p, 0, st, n_cu);
   if (use_wreg && NC % 64 == 0 && Din <= 128) {   // (Din = 256 needs 128 weight registers per lane and spills)
     // W-stationary persistent kernel: one 512-thread block per CU, column groups of 32*NCT in grid.y
@@ -1032,6 +1033,18 @@ extern "C" int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, in
   if (!sums) return BGNN_E_NULL;
   return transform_impl(x, N, Din, ldx, mask, nullptr, sums, n_heads, D, Wp, bias_p, gates, gate_const_opt,
                         h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream, n_tail_t2s, n_tail_s2t);
+}
+
+extern "C" int bgnn_adaptedconv_transform_need_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                                   const uint8_t* mask, const double* sums,
+                                                   int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                                   const float* gates, const float* gate_const_opt,
+                                                   float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                                   int64_t ldh, int64_t row_stride, const int32_t* tile_need_opt,
+                                                   float* small_ws, void* stream) {
+  if (!sums) return BGNN_E_NULL;
+  return transform_impl(x, N, Din, ldx, mask, nullptr, sums, n_heads, D, Wp, bias_p, gates, gate_const_opt,
+                        h_s2t_0, h_t2s_0, h_s2t_1, h_t2s_1, ldh, row_stride, small_ws, stream, 0, 0, tile_need_opt);
 }
 
 extern "C" int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W, const float* bias,

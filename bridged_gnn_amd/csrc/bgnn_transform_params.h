@@ -31,6 +31,11 @@ struct GemmParams {
   // SAME launch (three launches -- both / t2s-only / s2t-only -- measured slower than doing both tables everywhere).
   // Both = N: no tail.
   int64_t tail_t2s_begin, tail_s2t_begin;
+  // stream kernel, MODE 0, optional: one int32 per 32-row tile, bit t set = some row of the tile needs table t (0 = h_s2t, 1 = h_t2s).
+  // A node's h_t2s row is read only by source-domain destinations (and as its own row if it is one), its h_s2t row only by target-
+  // domain destinations: in a bridged graph with s -> t bridge edges no target node ever feeds a source destination, so half of
+  // the h_t2s table is dead (C4: 256 MB of writes and a quarter of the matrix work per forward).  nullptr: every tile needs both.
+  const int32_t* tile_need;
   // stream kernel, fused classifier stage: a second packed operand on the SAME input rows (the narrow tables of two convs that read
   // x directly -- clf_base / clf_target on h) evaluated by one more consumer wave of the launch; nullptr: absent
   const float* sk_Wp; const float* sk_bias; const float* sk_wd; const float* sk_g; const float* sk_gc;

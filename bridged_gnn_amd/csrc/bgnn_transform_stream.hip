@@ -366,6 +366,7 @@ __global__ __launch_bounds__(64 * NW) void transform_stream_kernel(GemmParams p)
       // single-table tail rows (GemmParams): a tile inside one tail group is sat out by the other table's waves
       const int64_t tb = tile * 32, te = tb + 32;
       skip = p.tail_s2t_begin > 0 && ((my_table == 0 && tb >= p.tail_t2s_begin && te <= p.tail_s2t_begin) || (my_table == 1 && tb >= p.tail_s2t_begin));
+      if (p.tile_need != nullptr) skip = skip || ((p.tile_need[tile] >> my_table) & 1) == 0;     // (scalar load: uniform address)
     }
     if (skip) {                               // wave-uniform
       lds_arrive(&done[slot]);
@@ -571,7 +572,12 @@ __global__ __launch_bounds__(64 * NW) void transform_stream_kernel(GemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) res[r] = 0.f;
       bool live = false;
-      if (steady_wave && i >= 0 && s < nlocal) {      // block-uniform per wave; no vector memory in either branch
+      bool wanted = true;                     // does any row of tile i need this wave's table?  (GemmParams::tile_need)
+      if constexpr (MODE == 0) {
+        if (p.tile_need != nullptr && i >= 0 && i < nlocal)
+          wanted = ((p.tile_need[blockIdx.x + i * (int64_t)gridDim.x] >> my_table) & 1) != 0;
+      }
+      if (steady_wave && wanted && i >= 0 && s < nlocal) {      // block-uniform per wave; no vector memory in either branch
         fused(i, rv, mk, ss, sr, cs, cr, pf_done, pf_ready, res);
         bump(ss, sr);
         bump(cs, cr);

@@ -103,6 +103,7 @@ class Linear(nn.Module):
         return F.linear(x, self.weight, self.bias)
 
 
+_TILE_NEED = os.environ.get("BGNN_TILE_NEED", "1") != "0"     # skip the transformed rows no destination reads (DstCSR.tile_need)
 _U8_CACHE = [None, -1, None]          # (weakref of the bool mask, its _version, uint8 copy)
 
 
@@ -471,7 +472,7 @@ class AdaptedConv(nn.Module):
             self._pack_key = key
         return self._pack
 
-    def transform(self, x, mask_u8, delta=None, sums=None, out=None, partner=None, tail_single=(0, 0)):
+    def transform(self, x, mask_u8, delta=None, sums=None, out=None, partner=None, tail_single=(0, 0), tile_need=None):
         """KTGNN.py:275-284 -> (h_t2s, h_s2t) [N, pad4(D)]; with `partner` (a second conv on the SAME
         input) -> [(h_t2s, h_s2t), (h_t2s', h_s2t')] from one pass over x."""
         xp = _pad_cols4(x)
@@ -481,7 +482,8 @@ class AdaptedConv(nn.Module):
         # with `sums` the kernel that forms W.delta also forms delta (bgnn_adaptedconv_transform_sums_f32)
         res = ops.adaptedconv_transform(xp, mask_u8, delta, self.packed(din_pad, partner),
                                         out=out if (out is None or partner is not None) else [out],
-                                        sums=sums if delta is None else None, tail_single=tail_single)
+                                        sums=sums if delta is None else None, tail_single=tail_single,
+                                        tile_need=tile_need if (delta is None and partner is None) else None)
         return res if partner is not None else res[0]
 
     def aggregate(self, h_t2s, h_s2t, csr, mask_u8, n_dst=None, want_alpha=False, epilogue=None, colsum=None):
@@ -545,7 +547,12 @@ class AdaptedConv(nn.Module):
                 out = out * sc + sh
                 out = F.relu(out) if relu else out
             return out
-        h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta, sums=sums)
+        # (no autograd here and the two tables never leave this function: rows of a table that no destination of THIS graph reads
+        #  need not be written -- DstCSR.tile_need)
+        if delta is None and sums is None:
+            sums = ops.domain_sums(_pad_cols4(x_src), mask_u8)
+        need = csr.tile_need(mask_u8) if (delta is None and csr.num_nodes == N and self.out_channels > 32 and _TILE_NEED) else None
+        h_t2s, h_s2t = self.transform(x_src, mask_u8, delta=delta, sums=sums, tile_need=need)
         fuse = epilogue if not (self.root_weight or self.normalize) else None
         if colsum is not None and (fuse is None and epilogue is not None or self.root_weight or self.normalize):
             raise ValueError("colsum needs the fused epilogue path")

@@ -68,6 +68,34 @@ class DstCSR:
             self._hubs[key] = DstCSR._hub_tables_of(self.transposed()[0], self.num_nodes, threshold, segment)
         return self._hubs[key]
 
+    def tile_need(self, mask_u8, rows_per_tile=32):
+        """Per 32-row tile: which of a node's two transformed rows does the aggregation over THIS graph ever read?  bit 0 = h_s2t
+        (gathered by target-domain destinations, KTGNN.py:293,:295), bit 1 = h_t2s (source-domain destinations, :292,:294); a
+        row's own table counts (the logit reads h_i).  -> int32 [ceil(N / 32)] for `adaptedconv_transform(tile_need=...)`, or
+        None when every tile needs both tables.  Built once per (graph, mask); with s -> t bridge edges only, no target node
+        feeds a source destination and the target half of h_t2s is never read."""
+        key = (mask_u8.data_ptr(), mask_u8._version, int(rows_per_tile))
+        c = getattr(self, "_tile_need", None)
+        if c is None or c[0] != key:
+            E, N = self.num_edges, self.num_nodes
+            m = mask_u8[:N].bool()
+            deg = (self.rowptr[1:N + 1] - self.rowptr[:N]).long()
+            dst_s = torch.repeat_interleave(m, deg)                       # domain of every edge's destination (by-destination order)
+            col = self.col[:E].long()
+            need_t2s, need_s2t = m.clone(), ~m
+            need_t2s[col[dst_s]] = True
+            need_s2t[col[~dst_s]] = True
+            T = (N + rows_per_tile - 1) // rows_per_tile
+            pad = T * rows_per_tile - N
+
+            def tiles(v):
+                v = torch.cat((v, v.new_zeros(pad))) if pad else v
+                return v.view(T, rows_per_tile).any(1)
+            need = (tiles(need_s2t).to(torch.int32) | (tiles(need_t2s).to(torch.int32) << 1)).contiguous()
+            full = bool((need == 3).all().item())                         # one-time sync, like the CSR build
+            self._tile_need = c = (key, None if full else need, mask_u8)  # (mask kept alive: the key holds its address)
+        return c[1]
+
     def transposed(self):
         """By-SOURCE view of the same edges, built once per graph (training only): (t_rowptr [N+1], t_eid [E'] = position
         of the edge in the by-destination order, t_dst [E'] = its destination), int32.  The atomic-free aggregation
@@ -390,9 +418,9 @@ def pack_transform_heads(heads, din_pad):
     return Wp, bp, gates, D, ldh, gconst
 
 
-def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None, tail_single=(0, 0)):
+def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None, tail_single=(0, 0), tile_need=None):
     """One pass over x -> per head (h_t2s, h_s2t) as [N, ldh] tensors (ldh = pad4(D); columns >= D are
-    zero).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
+    zero; `tile_need`: see DstCSR.tile_need).  `packed` = pack_transform_heads(...).  `out` = list of (h_t2s, h_s2t) preallocated tables
     (>= N rows, row stride ldh; multi-GPU: halo rows follow the N local rows).  With `delta=None` the domain
     `sums` ([2*Din+2] float64) are consumed directly (same delta, one launch less).  `tail_single=(n_t2s, n_s2t)`
     (sums form only): the last n_t2s + n_s2t rows need only h_t2s / only h_s2t; their other table may stay unwritten."""
@@ -418,6 +446,13 @@ def adaptedconv_transform(x, mask_u8, delta, packed, out=None, sums=None, tail_s
     tail = (int(tail_single[0]), int(tail_single[1])) if delta is None else ()
     if delta is not None and tuple(tail_single) != (0, 0):
         raise ValueError("tail_single needs the sums form of the transform")
+    if tile_need is not None:
+        # `tile_need` (DstCSR.tile_need): rows of a table that the aggregation never reads may stay unwritten (sums form only)
+        if delta is not None or tuple(tail_single) != (0, 0):
+            raise ValueError("tile_need needs the sums form of the transform and no tail_single")
+        if tile_need.dtype != torch.int32 or tile_need.numel() != (N + 31) // 32:
+            raise ValueError("tile_need: one int32 per 32-row tile")
+        fn, name, tail = lib.bgnn_adaptedconv_transform_need_f32, "bgnn_adaptedconv_transform_need_f32", (L.ptr(tile_need),)
     rc = fn(L.ptr(x), N, Din, x.stride(0), L.ptr(mask_u8), L.ptr(first), H, D, L.ptr(Wp), L.ptr(bp), L.ptr(gates), L.ptr(gconst),
             L.ptr_rows(out[0][1]), L.ptr_rows(out[0][0]), L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride, *tail,
             L.ptr(small), L.stream())

@@ -25,8 +25,9 @@ extern "C" {
 
 /* ABI revision.  110 (round 3) is NOT call-compatible with 100: `bgnn_transform_bwd_prep_f32` takes 22 arguments (was 17)
  * and the `n_fallback_opt` of `bgnn_cosine_topk_f32` / `bgnn_mlp_pair_topk_f32` is int32[2] (was int32[1]) -- a caller built
- * against the old header must be recompiled; compare bgnn_version() with the BGNN_VERSION it was built with at load time. */
-#define BGNN_VERSION 110
+ * against the old header must be recompiled; compare bgnn_version() with the BGNN_VERSION it was built with at load time.
+ * 111 adds bgnn_adaptedconv_transform_need_f32 (call-compatible with 110). */
+#define BGNN_VERSION 111
 #define BGNN_E_NULL (-1)        /* required pointer is NULL                     */
 #define BGNN_E_SHAPE (-2)       /* unsupported / inconsistent shape             */
 #define BGNN_E_WORKSPACE (-3)   /* ws_bytes smaller than *_workspace_bytes()    */
@@ -190,6 +191,18 @@ int bgnn_adaptedconv_transform_sums_f32(const float* x, int64_t N, int32_t Din, 
                                         const float* gates, const float* gate_const_opt,
                                         float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
                                         int64_t ldh, int64_t row_stride, int64_t n_tail_t2s, int64_t n_tail_s2t,
+                                        float* small_ws, void* stream);
+/* The sums form with a per-tile need mask (ABI 111).  tile_need_opt: NULL, or one int32 per 32-row tile of x, bit 0 set = some row
+ * of the tile has its h_s2t row read by the aggregation, bit 1 = its h_t2s row (a node's h_t2s row is gathered only by source-
+ * domain destinations and as the node's own row if it is one, KTGNN.py:292-295; with s -> t bridge edges no target node feeds a
+ * source destination and half of the h_t2s table is dead).  Rows of a table that no tile needs MAY be left unwritten.  Only the
+ * stream kernel (one head, 128 / 256 packed columns, 64 < Din <= 128) honours the mask; other shapes write both tables. */
+int bgnn_adaptedconv_transform_need_f32(const float* x, int64_t N, int32_t Din, int64_t ldx,
+                                        const uint8_t* mask, const double* sums,
+                                        int32_t n_heads, int32_t D, const float* Wp, const float* bias_p,
+                                        const float* gates, const float* gate_const_opt,
+                                        float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1,
+                                        int64_t ldh, int64_t row_stride, const int32_t* tile_need_opt,
                                         float* small_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
