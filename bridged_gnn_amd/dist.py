@@ -157,6 +157,19 @@ class PartitionPlan:
         # index into the [h_s2t local | h_t2s local] region: h_t2s (table 0) rows live at n_local + r
         self.send_rows = g2l[s_id] + np.where(s_table == 0, self.n_local, 0)
         self.send_rows_local = g2l[s_id]                         # the same rows as plain local row numbers (input features)
+        # ---- all-gather fallback ("a plain all_gather of [N/P, D] blocks when the halo ~ N").  Every rank
+        #      contributes its two tables in ascending-global-id order (h_s2t block, then h_t2s block, padded to the largest
+        #      rank); a halo slot (owner o, table t, node v) is then row  o * 2 * nmax + (t == 0) * nmax + rank_in_owner[v]
+        counts = np.bincount(owner, minlength=world).astype(np.int64)
+        self.n_local_max = int(counts.max())
+        order_all = np.argsort(owner, kind="stable")             # nodes grouped by owner, ascending id inside a group
+        rank_in_owner = np.empty(N, dtype=np.int64)
+        rank_in_owner[order_all] = np.arange(N) - np.repeat(np.cumsum(counts) - counts, counts)
+        self.gather_index = (r_owner.astype(np.int64) * 2 * self.n_local_max + np.where(r_table == 0, self.n_local_max, 0)
+                             + rank_in_owner[r_id])
+        self.sorted_local = g2l[mine]                            # local row of the k-th owned node in ascending-id order
+        # payload of the two forms in rows: pack + all_to_all moves n_halo rows in, the all-gather 2 * nmax * (world - 1)
+        self.halo_fraction = self.n_halo / max(2.0 * self.n_local_max * max(world - 1, 1), 1.0)
         # ---- local CSR (stable: input order inside a row, self loop last) ---------------------------
         keep = o_dst == rank
         ls, ld, lt = src[keep], dst[keep], table[keep]
@@ -206,9 +219,17 @@ class HaloExchange:
     `all_to_all_single` with uneven splits per conv, posted asynchronously by `start`, awaited by `wait`;
     received rows land directly in big[2*n_local:]."""
 
-    def __init__(self, plan, device, group=None, always=False):
+    ALLGATHER_FROM = 0.6      # `mode="auto"`: all-gather once the halo holds >= 60 % of everybody else's rows (both tables)
+
+    def __init__(self, plan, device, group=None, always=False, mode="auto"):
+        """mode: "a2a" = row pack + all_to_all of the referenced rows; "allgather" = every rank's whole [2 n_local, ld] block
+        (SURVEY 8(e)'s fallback for graphs whose halo is ~ everything: no pack kernel, no uneven splits, one dense collective, at
+        up to 1 / halo_fraction times the bytes); "auto" picks by `plan.halo_fraction`."""
         self.plan, self.group, self.always = plan, group, always   # always: issue the collectives even at world 1
+        self.mode = mode if mode != "auto" else ("allgather" if plan.halo_fraction >= self.ALLGATHER_FROM and plan.world > 1 else "a2a")
         self.send_rows = torch.from_numpy(plan.send_rows).to(device)
+        self.gather_index = torch.from_numpy(plan.gather_index).to(device)
+        self.sorted_rows = torch.cat((torch.from_numpy(plan.sorted_local), torch.from_numpy(plan.sorted_local) + plan.n_local)).to(device)
         self._work, self._keep = None, None
         # gloo cannot move device memory: when the process group is gloo but the tables live on a GPU (debug /
         # single-GPU multi-process rehearsals) the payload is staged through the host.  RCCL never takes this path.
@@ -218,6 +239,8 @@ class HaloExchange:
     def start(self, big):
         """big = [h_s2t local | h_t2s local | halo] ([2*n_local + n_halo, ld]); the local rows must be final."""
         p = self.plan
+        if self.mode == "allgather" and (p.world > 1 or self.always):
+            return self._start_allgather(big)
         if big.is_cuda and big.dtype == torch.float32 and big.shape[1] % 4 == 0 and big.stride(1) == 1:
             from . import ops
             send = ops.gather_rows(big, self.send_rows)              # [sum(send_splits), ld]
@@ -237,9 +260,36 @@ class HaloExchange:
         self._work = dist.all_to_all_single(recv, send, output_split_sizes=p.recv_splits,
                                             input_split_sizes=p.send_splits, group=self.group, async_op=True)
 
+    def _start_allgather(self, big):
+        """the fallback: [h_s2t sorted | h_t2s sorted] of every rank in one all_gather; the referenced rows are picked out of
+        the gathered buffer in `wait` (the aggregation of the local-source edges runs in between, as with the all_to_all)"""
+        p = self.plan
+        ld = big.shape[1]
+        blk = torch.zeros(2 * p.n_local_max, ld, dtype=big.dtype, device=big.device)
+        rows = big.index_select(0, self.sorted_rows)                 # [2 n_local, ld]: h_s2t rows, then h_t2s rows, ascending ids
+        blk[:p.n_local] = rows[:p.n_local]
+        blk[p.n_local_max:p.n_local_max + p.n_local] = rows[p.n_local:]
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self.host_staging:
+            out = torch.empty(world * 2 * p.n_local_max, ld, dtype=big.dtype)
+            dist.all_gather_into_tensor(out, blk.cpu(), group=self.group)
+            self._gathered = (out.to(big.device), big)
+            self._work = None
+        else:
+            out = torch.empty(world * 2 * p.n_local_max, ld, dtype=big.dtype, device=big.device)
+            self._work = dist.all_gather_into_tensor(out, blk, group=self.group, async_op=True)
+            self._gathered = (out, big)
+        self._keep = blk
+
     def wait(self):
         if self._work is not None:
             self._work.wait()
+        g = getattr(self, "_gathered", None)
+        if g is not None:
+            out, big = g
+            p = self.plan
+            big[2 * p.n_local: 2 * p.n_local + p.n_halo] = out.index_select(0, self.gather_index)
+            self._gathered = None
         self._work, self._keep = None, None
 
     def exchange_rows(self, rows):
@@ -264,7 +314,7 @@ class PartitionedKTGNN:
     """Eval forward of `KTGNN_no_complement` (models/KTGNN.py:401-435) on rank-local rows."""
 
     def __init__(self, model, edge_index, central_mask, rank, world, device, owner=None, group=None,
-                 always_communicate=False, cache_input_halo=True):
+                 always_communicate=False, cache_input_halo=True, halo_mode="auto"):
         from . import ops
         # cache_input_halo: the FIRST conv reads the graph's input features, which do not change between forwards (the
         # reference trains 300 epochs on one `data.x`).  Their halo rows are fetched once per version of x (same send
@@ -295,7 +345,7 @@ class PartitionedKTGNN:
         self._state3 = None
         self.mask_local = torch.from_numpy(plan.mask_local).to(device)
         self.mask_u8 = self.mask_local.to(torch.uint8).contiguous()
-        self.halo = HaloExchange(plan, device, group, always=always_communicate)
+        self.halo = HaloExchange(plan, device, group, always=always_communicate, mode=halo_mode)
 
     def _all_reduce(self, t):
         if self.halo.host_staging:                                   # gloo rehearsal on GPU tensors (see HaloExchange)

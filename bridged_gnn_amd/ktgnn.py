@@ -259,7 +259,11 @@ class _TransformFn(torch.autograd.Function):
       g = tanh(x.a_x + D.a_d) per gate,  D = mean_S x - mean_T x (a function of every row)."""
 
     @staticmethod
-    def forward(ctx, x, W_s, b_s, W_t, b_t, ag_s2t, ag_t2s, mask_u8, conv, sums=None):
+    def forward(ctx, x, W_s, b_s, W_t, b_t, ag_s2t, ag_t2s, mask_u8, conv, sums=None, mean_hook=None):
+        # `mean_hook` (partitioned training, dist_train.py): `sums` are the ALL-REDUCED domain sums, so the gradient through the
+        # domain means is a global quantity -- the backward hands the local adjoint of delta ([Din]) to the hook, which returns the
+        # [N, Din] term to add to dX (the all-reduced adjoint times +1/n_S | -1/n_T on the rows this rank owns)
+        ctx.mean_hook = mean_hook
         xp = _pad_cols4(x)
         din_pad = xp.shape[1]
         if sums is None:                 # `sums`: the domain sums of this x if another conv on the same input already has them
@@ -278,6 +282,8 @@ class _TransformFn(torch.autograd.Function):
         g1, g2 = ag_s2t.reshape(-1), ag_t2s.reshape(-1)
         fast = x.stride(1) == 1 and x.stride(0) % 4 == 0 and din % 4 == 0 and x.data_ptr() % 16 == 0 and din <= 128 and D <= 128
         p3 = ops.pad4(2 * D + 3)
+        if ctx.mean_hook is not None:           # (gradient rows that come back as column slices of an exchanged block)
+            G_t2s, G_s2t = G_t2s.contiguous(), G_s2t.contiguous()
         if (fast and G_s2t.is_contiguous() and G_t2s.is_contiguous() and G_s2t.dtype == torch.float32
                 and G_s2t.stride(0) == G_t2s.stride(0) and ops.gram_supported(p3, din)
                 and (not ctx.needs_input_grad[0] or ops.linear_supported(p3, din))):
@@ -290,9 +296,16 @@ class _TransformFn(torch.autograd.Function):
             dWall = ops.gram(Gall, x)
             wcat_t = torch.empty(din, p3, dtype=torch.float32, device=x.device)
             dW_s, dW_t, dg1, dg2, db_s, db_t = ops.transform_bwd_finish(dWall, ex, Ws, Wt, g1c, g2c, delta, din, wcat_t)
-            dX = ops.linear(Gall, wcat_t, x.new_zeros(din)) if ctx.needs_input_grad[0] else None
+            dX = None
+            if ctx.needs_input_grad[0]:
+                if ctx.mean_hook is not None:
+                    ddl = wcat_t[:, 2 * D + 2].clone()                         # local adjoint of delta (bgnn_gram.hip: wcat_t layout)
+                    wcat_t[:, 2 * D + 2] = 0
+                dX = ops.linear(Gall, wcat_t, x.new_zeros(din))
+                if ctx.mean_hook is not None:
+                    dX = dX + ctx.mean_hook(ddl)
             return (dX, dW_s, db_s if ctx.has_bias[0] else None, dW_t, db_t if ctx.has_bias[1] else None,
-                    dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None)
+                    dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None, None)
         m = mask_u8.bool()
         dl = delta[:din]
         n_s, n_t = sums[-2].float(), sums[-1].float()
@@ -347,17 +360,19 @@ class _TransformFn(torch.autograd.Function):
             Wcat = x.new_zeros(p, din)                                          # rows: W_t, W_s, g1_x, g2_x
             Wcat[:D], Wcat[D:2 * D], Wcat[2 * D], Wcat[2 * D + 1] = W_t, W_s, g1[:din], g2[:din]
             ddl = sp[0] * g1[din:] + sp[1] * g2[din:] - W_t.t() @ u1 + W_s.t() @ u2
-            if fused_prep:
+            if fused_prep and ctx.mean_hook is None:
                 Wcat[2 * D + 2] = ddl                                           # x Gall[:, 2D+2] = +-1/n: through the domain means
             if ops.linear_supported(p, din):
                 dX = ops.linear(Gall, Wcat.t().contiguous(), x.new_zeros(din))  # skinny K: the W-stationary MFMA kernel
             else:
                 dX = Gall @ Wcat
-            if not fused_prep:
+            if ctx.mean_hook is not None:
+                dX = dX + ctx.mean_hook(ddl)                                    # partitioned: the all-reduced adjoint, owned rows only
+            elif not fused_prep:
                 dX = dX + torch.where(m, 1.0 / n_s, -1.0 / n_t)[:, None] * ddl[None, :]   # through the domain means
         db_s = ex[D:2 * D, 2] if ctx.has_bias[0] else None
         db_t = ex[:D, 2] if ctx.has_bias[1] else None
-        return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None
+        return dX, dW_s, db_s, dW_t, db_t, dg1.reshape(ag_s2t.shape), dg2.reshape(ag_t2s.shape), None, None, None, None
 
 
 class _TransformPairFn(torch.autograd.Function):
@@ -495,10 +510,10 @@ class AdaptedConv(nn.Module):
                                          self.negative_slope, n_dst=n_dst, want_alpha=want_alpha,
                                          ep_scale=sc, ep_shift=sh, ep_relu=relu, colsum=colsum)
 
-    def _transform_autograd(self, x, mask_u8, sums=None):
+    def _transform_autograd(self, x, mask_u8, sums=None, mean_hook=None):
         """the differentiable transform alone -> (h_t2s, h_s2t) [N, pad4(D)]"""
         return _TransformFn.apply(x, self.lin_s.weight, self.lin_s.bias, self.lin_t.weight, self.lin_t.bias,
-                                  self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self, sums)
+                                  self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self, sums, mean_hook)
 
     def _forward_autograd(self, x, mask, mask_u8, csr):
         """Differentiable path: fused HIP transform + fused HIP aggregation, each a `torch.autograd.Function`."""

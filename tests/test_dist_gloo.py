@@ -114,6 +114,13 @@ def _worker(rank, world, port, q):
         hx.wait()
         out = _aggregate_big(p, big.numpy(), a1, a2)
         ok = bool(np.array_equal(out, ref[p.owned_global]))
+        # SURVEY 8(e)'s fallback: the same halo out of ONE all_gather of every rank's [2 n_local, D] block
+        big2 = torch.from_numpy(_fill_local(p, h_t2s, h_s2t, D))
+        hg = HaloExchange(p, "cpu", mode="allgather")
+        hg.start(big2)
+        hg.wait()
+        ok = ok and bool(np.array_equal(big2.numpy(), big.numpy())) and hg.mode == "allgather"
+        ok = ok and HaloExchange(p, "cpu").mode == ("allgather" if p.halo_fraction >= HaloExchange.ALLGATHER_FROM else "a2a")
         # input-feature halo (fetched once per version of x): owners send plain local rows, slots arrive in halo order
         feat = np.random.default_rng(9).standard_normal((mask.shape[0], 8)).astype(np.float32)
         mine = torch.from_numpy(feat[p.owned_global])
