@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=-1,
                     help="also time this many training steps (fwd+bwd+Adam, reference loss); default: 5 for config c4 on one GPU, else 0")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned (RCCL) code path even at world size 1")
+    ap.add_argument("--no-partitioned-check", action="store_true",
+                    help="N=1: skip timing the same forward through the partitioned driver at world size 1 (`partitioned_path_n1`)")
     ap.add_argument("--no-input-halo-cache", action="store_true",
                     help="N>1: exchange transformed rows for the first conv on every forward instead of keeping the halo rows "
                          "of the (static) input features resident and transforming them locally")
@@ -603,6 +605,29 @@ def main():
                    "fabric_frac": (tr_u / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr_u else None, "edges": e_u}
         del model_u, data_u
 
+    # N=1 through the partitioned driver (no process group, world size 1): the path the N>1 runs take must cost what the plain
+    # forward costs when there is nothing to exchange (VERDICT r2 #4d: within 3 %)
+    part_n1 = None
+    if not use_dist and args.config == "c4" and not args.no_partitioned_check:
+        from bridged_gnn_amd.dist import PartitionedKTGNN
+        t0 = time.perf_counter()
+        pk1 = PartitionedKTGNN(model, ei_np, mask_np, 0, 1, dev)
+        torch.cuda.synchronize()
+        plan_s = time.perf_counter() - t0
+        x1 = wl["x"][pk1.owned_global].contiguous()
+        with torch.no_grad():
+            for _ in range(5):
+                o1 = pk1.forward(x1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                o1 = pk1.forward(x1)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t0) / args.steps * 1e3
+            inv = torch.empty_like(pk1.owned_global); inv[pk1.owned_global] = torch.arange(N, device=dev)
+            err = max(float((a[inv] - b).abs().max()) for a, b in zip(o1, gpu_out))
+        part_n1 = {"ms_per_step": ms1, "vs_plain": ms1 / ms_step, "plan_build_s": plan_s, "max_abs_diff_vs_plain_outputs": err}
+        del pk1, x1, o1
     train = None
     if args.train_steps < 0:
         args.train_steps = 5 if (args.config == "c4" and not use_dist) else 0
@@ -721,6 +746,13 @@ def main():
                                          (" (this rank's rows)" if use_dist else ""),
                                  "base": checksums[0], "target": checksums[1], "target_hat": checksums[2]},
         }
+        if part_n1 is not None:
+            out["partitioned_path_n1"] = part_n1
+        if use_dist:
+            out["config"]["plan_build_s"] = csr_ms / 1e3
+            out["config"]["world_size_seen"] = torch.distributed.get_world_size()
+            out["config"]["dist_backend"] = torch.distributed.get_backend()
+            out["config"]["halo_exchange"] = pk.halo.mode
         if knn is not None:
             out["knn"] = knn
         if train is not None:
