@@ -1134,6 +1134,12 @@ extern "C" int bgnn_linear_narrow_transform_f32(const float* x, int64_t N, int32
     int dev = 0; hipDeviceProp_t prop;
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }();
+  // The barrier-free pipeline's form of this launch (transform_stream2_kernel) is OPT-IN (BGNN_GEMM_STREAM2=1): measured
+  // 0.270 ms against this kernel's 0.254-0.276 ms on C4 -- its waves spend the time the block kernel spends at barriers waiting
+  // at the ring's counters instead (profiles/r03/README.md); same results, kept for the next round's work on the tail behind
+  // the first-stage MFMAs.
+  static const bool use_stream2 = [] { const char* e = getenv("BGNN_GEMM_STREAM2"); return e && atoi(e) != 0; }();
+  if (use_stream2 && bgnn_tf_stream_supported(p, 2)) return bgnn_tf_stream_launch(p, 2, st, n_cu);
   const int nct = Dout == 256 ? 8 : Dout == 128 ? 4 : 2;
   const int nw = nct == 2 ? 4 : 8;
   const int bmw = 32 * (nw / nct);

@@ -462,7 +462,11 @@ __global__ __launch_bounds__(64 * NW) void transform_stream_kernel(GemmParams p)
         const int kb = 2 * b + t;
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr) {
+#ifndef TS_X_NOMFMA
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? fa[b & 1][t][1] : fa[b & 1][t][0], pr == 1 ? wlo[kb] : whi[kb], acc, 0, 0, 0);
+#else
+          if (pr == 0) acc[kb] += (float)fa[b & 1][t][0][0] + (float)fa[b & 1][t][1][1];     // ablation: keep the fragment reads alive
+#endif
           if (step < STAGE_STEPS) {
             stage_step(q, step, wb, 0);
           } else if (step < STAGE_STEPS + 4) {
@@ -503,7 +507,11 @@ __global__ __launch_bounds__(64 * NW) void transform_stream_kernel(GemmParams p)
   int64_t st_left = 0;                        // N - first row of the tile stored next (set where the loop starts)
   const float* st_o = otab;
   auto store16 = [&](bool live, const float (&res)[16]) {
+#ifdef TS_X_NOSTORE
+    const int rows_here = 0;                  // ablation: every store dropped by the range check
+#else
     const int rows_here = (!live || st_left < 0) ? 0 : (st_left > 32 ? 32 : (int)st_left);
+#endif
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st_o), (short)0, rows_here * rs4, 0x00020000);
     st_left -= tstep; st_o += tstep * p.row_stride;
 #ifdef TS_X_STORE4
@@ -609,9 +617,445 @@ __global__ __launch_bounds__(64 * NW) void transform_stream_kernel(GemmParams p)
 #endif
 }
 
+
+// ======================================================================================================================
+// Linear -> ReLU -> narrow AdaptedConv transform in the same pipeline (KTGNN_no_complement.forward :433: clf_target on
+// clf_transformer(h); stage A of bgnn_linear_narrow_transform_f32).  The activation a1 = relu(x W^T + b) of a tile never
+// leaves the registers: NA = 4 waves own 32 of its 128 columns each, here with W as the MFMA's A operand, so that a lane ends
+// up with 16 columns of ONE row -- which is the B operand of the second stage as it stands (k slot = register index).  The
+// second stage (6 fp16 MFMAs per wave against the stationary 10 x 32 slice of the consumer conv's packed rows and gate vectors)
+// leaves 12 partial sums per row in the tile's LDS slot of that wave; the wave whose arrival completes the slot's counter adds
+// the four slices and stores the tile's 32 x 12 floats.  The per-domain column sums of a1 (the next delta) accumulate per lane
+// (fp32, ~120 rows per lane) and are reduced once at the end.  The W operands get ONE power-of-two scale per matrix (a lane's
+// registers hold 16 different columns, so per-column scales do not factor out); rows are scaled per row as in the transform.
+// All waves issue the same vector-memory instructions per iteration (3 loads, 2 stores; empty descriptors where a wave has
+// nothing to store), see the header comment.
+template <int DK, int NW, int NA, int SLOTS, int AHEAD, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void transform_stream2_kernel(GemmParams p) {
+  using SL = Slot<DK>;
+  static_assert(DK == 128 && NW == 8 && AHEAD >= 1 && AHEAD < SLOTS, "pipeline shape");
+  constexpr int KB16 = DK / 16, CPT = DK / 64, RPW = 32 / NW;
+  constexpr int R2 = 12;                      // floats per row of a partial / of the raw output
+  __shared__ __attribute__((aligned(16))) unsigned char ring[SLOTS * SL::BYTES];
+  __shared__ __attribute__((aligned(16))) float red[SLOTS][NA][32 * R2];
+  __shared__ uint32_t ready[SLOTS], done[SLOTS], redcnt[SLOTS], wmax[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < SLOTS) { ready[tid] = 0u; done[tid] = 0u; redcnt[tid] = 0u; }
+  if (tid < 2) wmax[tid] = 0u;
+  __syncthreads();
+  const int64_t ntiles = (p.N + 31) / 32;
+  const int64_t nlocal = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  // two teams of NA waves (waves 0..3 / 4..7, one of each per SIMD) take the tiles in turn: the long tail behind a tile's first-stage
+  // MFMAs (activation, column sums, split, second stage, reduction) then overlaps with the partner's next chain instead of
+  // running beside an idle wave (one team of 4 consumers + 4 staging-only waves measured 0.27 ms, no better than the block kernel)
+  static_assert(NW == 2 * NA, "two consumer teams");
+  const bool consumer = true;
+  const int team = wave / NA, cw = wave % NA;
+  const int NC = p.NC;                        // = 32 * NA
+#ifdef TS_STAMP
+  uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t st_last = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+
+  // ---------------------------------------------------------------- staging (no gates here: the coefficient block carries the
+  // row's inverse scale and its domain flag)
+  const int l16 = lane & 15, rsub = lane >> 4;
+  const bool din_full = p.Din == DK;
+  int woff[CPT], xoff[CPT];
+  const int srow = RPW * wave + rsub;
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int c4 = l16 + 16 * c, k = c4 * 4;
+    woff[c] = SL::chunk_off(srow, c4 >> 1) + ((c4 & 1) << 3);
+    xoff[c] = (int)((srow * p.ldx + (din_full || k < p.Din ? k : 0)) * 4);
+  }
+  const int coff = l16 < 4 ? 32 * l16 + srow : 128 + srow;
+  u32x4 ra[DEPTH][CPT];
+  uint8_t rm[DEPTH];
+  const int64_t tstep = (int64_t)gridDim.x * 32;
+  int64_t rq_left = p.N - (int64_t)blockIdx.x * 32;
+  const float* rq_x = p.x + (int64_t)blockIdx.x * 32 * p.ldx;
+  const uint8_t* rq_m = p.mask + (int64_t)blockIdx.x * 32;
+  auto request = [&](int set) {
+    const int rows_here = rq_left > 32 ? 32 : (rq_left < 0 ? 0 : (int)rq_left);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rq_x), (short)0, rows_here * (int)p.ldx * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(rq_m), (short)0, rows_here, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) ra[set][c] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[c], 0, 0);
+    rm[set] = __builtin_amdgcn_raw_buffer_load_b8(rmk, srow, 0, 0);
+    rq_left -= tstep; rq_x += tstep * p.ldx; rq_m += tstep;
+  };
+  struct StageState { float f[4 * CPT]; bool sdom; float mx, sc, inv; h4 hi[CPT], lo[CPT]; };
+  constexpr int STAGE_STEPS = 4 + 3 * CPT + 1;
+  auto stage_step = [&](StageState& q, int m, unsigned char* sb) {
+    if (m == 0) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        q.mx = fmaxf(fmaxf(fabsf(q.f[4 * c]), fabsf(q.f[4 * c + 1])), q.mx);
+        q.mx = fmaxf(fmaxf(fabsf(q.f[4 * c + 2]), fabsf(q.f[4 * c + 3])), q.mx);
+      }
+    } else if (m == 1) {
+      unsigned b = __builtin_bit_cast(unsigned, q.mx);
+      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true));
+      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true));
+      q.mx = __builtin_bit_cast(float, b);
+    } else if (m == 2) {
+      unsigned b = __builtin_bit_cast(unsigned, q.mx);
+      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xF, 0xF, true));
+      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xF, 0xF, true));
+      q.mx = __builtin_bit_cast(float, b);
+    } else if (m == 3) {
+      pow2_scales(q.mx, q.sc, q.inv);
+    } else if (m < 4 + 3 * CPT) {
+      const int c = (m - 4) / 3, part = (m - 4) % 3;
+      if (part == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.hi[c][e] = (_Float16)(q.f[4 * c + e] * q.sc);
+      } else if (part == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.lo[c][e] = (_Float16)fmaf(q.f[4 * c + e], q.sc, -(float)q.hi[c][e]);
+      } else {
+        *reinterpret_cast<h4*>(sb + woff[c]) = q.hi[c];
+        *reinterpret_cast<h4*>(sb + SL::PIECE + woff[c]) = q.lo[c];
+      }
+    } else {
+      float val = l16 == 2 ? q.inv : 0.f;
+      val = l16 >= 3 ? (q.sdom ? 1.f : 0.f) : val;
+      reinterpret_cast<float*>(sb + SL::COEF)[coff] = val;
+    }
+  };
+  auto stage_init = [&](StageState& q, const u32x4 (&rv)[CPT], uint8_t mk) {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      float4 v = __builtin_bit_cast(float4, rv[c]);
+      if (!din_full && (l16 + 16 * c) * 4 >= p.Din) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      q.f[4 * c] = v.x; q.f[4 * c + 1] = v.y; q.f[4 * c + 2] = v.z; q.f[4 * c + 3] = v.w;
+    }
+    q.sdom = mk != 0; q.mx = 0.f; q.sc = q.inv = 0.f;
+  };
+  auto stage = [&](int64_t j, const u32x4 (&rv)[CPT], uint8_t mk, int slot, uint32_t round) {
+    if (j >= nlocal) return;
+    lds_wait_ge(&done[slot], (uint32_t)NA * round);
+    unsigned char* const sb = ring + slot * SL::BYTES;
+    StageState q;
+    stage_init(q, rv, mk);
+#pragma unroll
+    for (int m = 0; m < STAGE_STEPS; ++m) stage_step(q, m, sb);
+    lds_arrive(&ready[slot]);
+  };
+
+  // ---------------------------------------------------------------- consumer state
+  const int fr = lane & 31, fh = lane >> 5;
+  const int col_base = cw * 32;
+  h8 whi[KB16], wlo[KB16];                    // stationary A operand: W[col_base + fr][16kb + 8fh .. +7]
+  h8 w2h[2], w2l[2];                          // second stage, stationary A operand: row fr of (w2 | g2), k slot r = column col_base + 8(r/4) + 4fh + r%4
+  float bias16[16];
+  float cinvW = 0.f, cinvW2 = 0.f;
+  float cs_s[16], cs_t[16], cnt_s = 0.f, cnt_t = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { cs_s[r] = cs_t[r] = 0.f; bias16[r] = 0.f; }
+  {
+    float4 w[KB16][2];
+    float w2v[16];
+    float mx = 0.f, mx2 = 0.f;
+    if (consumer) {
+#pragma unroll
+      for (int kb = 0; kb < KB16; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int k = 16 * kb + 8 * fh + 4 * hf;
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k < p.Din) t = *reinterpret_cast<const float4*>(p.Wp + (int64_t)(col_base + fr) * p.Din + k);
+          w[kb][hf] = t;
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = col_base + 8 * (r >> 2) + 4 * fh + (r & 3);
+        float v = 0.f;
+        if (fr < 8) v = p.w2[(int64_t)fr * NC + c];
+        else if (fr < 10) v = p.g2[(int64_t)(fr - 8) * 2 * NC + c];
+        w2v[r] = v;
+        mx2 = fmaxf(mx2, fabsf(v));
+        bias16[r] = p.bias[c];
+      }
+      mx = bgnn::group_max<64>(mx);
+      mx2 = bgnn::group_max<64>(mx2);
+      if (lane == 0) { atomicMax(&wmax[0], __builtin_bit_cast(unsigned, mx)); atomicMax(&wmax[1], __builtin_bit_cast(unsigned, mx2)); }
+    }
+    __syncthreads();                          // one scale per matrix: the largest magnitude over all NA waves' slices
+    if (consumer) {
+      float sc, sc2;
+      pow2_scales(__builtin_bit_cast(float, wmax[0]), sc, cinvW);
+      pow2_scales(__builtin_bit_cast(float, wmax[1]), sc2, cinvW2);
+#pragma unroll
+      for (int kb = 0; kb < KB16; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          h4 hi, lo;
+          split4(w[kb][hf], sc, hi, lo);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { whi[kb][4 * hf + e] = hi[e]; wlo[kb][4 * hf + e] = lo[e]; }
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const _Float16 h = (_Float16)(w2v[r] * sc2);
+        w2h[r >> 3][r & 7] = h;
+        w2l[r >> 3][r & 7] = (_Float16)fmaf(w2v[r], sc2, -(float)h);
+      }
+    }
+  }
+  const int roff0 = SL::chunk_off(fr, fh);
+  auto roff = [&](int kb) { return roff0 ^ (kb << 5); };
+
+  // everything after the first-stage accumulators of a tile: activation, column sums, second stage, partial sums into the slot's
+  // reduction block; -> true (with the tile's two float4 items of this lane in o0 / o1) for the wave that completes the block
+  auto post = [&](const f32x16& acc, float s_row, float dom, int64_t tile, int slot, uint32_t round, float4& o0, float4& o1) -> bool {
+    float a1[16];
+    const float sc1 = s_row * cinvW;
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = fmaf(acc[r], sc1, bias16[r]);
+      if (p.relu) v = fmaxf(v, 0.f);
+      a1[r] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
+    const bool valid = tile * 32 + fr < p.N;
+    const float ws = (valid && dom != 0.f) ? 1.f : 0.f, wt = (valid && dom == 0.f) ? 1.f : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cs_s[r] = fmaf(ws, a1[r], cs_s[r]); cs_t[r] = fmaf(wt, a1[r], cs_t[r]); }
+    if (fh == 0) { cnt_s += ws; cnt_t += wt; }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));       // the row's two lane halves share the scale
+    float sc2, inv2;
+    pow2_scales(mx, sc2, inv2);
+    h8 ah[2], al[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const _Float16 h = (_Float16)(a1[r] * sc2);
+      ah[r >> 3][r & 7] = h;
+      al[r >> 3][r & 7] = (_Float16)fmaf(a1[r], sc2, -(float)h);
+    }
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[kb], al[kb], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[kb], ah[kb], acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[kb], ah[kb], acc2, 0, 0, 0);
+    }
+    // accumulator register i of lane (fr, fh) is output 8*(i/4) + 4*fh + i%4 of row fr: lane half 0 holds outputs 0..3 and
+    // 8..11 (8, 9 are the gate products), lane half 1 outputs 4..7
+    const float s2 = inv2 * cinvW2;
+    float* r2 = &red[slot][cw][fr * R2];
+    if (fh == 0) {
+      *reinterpret_cast<float4*>(r2) = make_float4(acc2[0] * s2, acc2[1] * s2, acc2[2] * s2, acc2[3] * s2);
+      *reinterpret_cast<float4*>(r2 + 8) = make_float4(acc2[4] * s2, acc2[5] * s2, 0.f, 0.f);
+    } else {
+      *reinterpret_cast<float4*>(r2 + 4) = make_float4(acc2[0] * s2, acc2[1] * s2, acc2[2] * s2, acc2[3] * s2);
+    }
+    TS_MARK(4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    uint32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&redcnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    const bool last = old == (uint32_t)NA * (round + 1) - 1;
+    if (last) {                               // wave-uniform: this wave adds the NA slices of the tile
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      o0 = *reinterpret_cast<const float4*>(&red[slot][0][lane * 4]);
+      o1 = lane < 32 ? *reinterpret_cast<const float4*>(&red[slot][0][(lane + 64) * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 1; w < NA; ++w) {
+        const float4 u = *reinterpret_cast<const float4*>(&red[slot][w][lane * 4]);
+        o0.x += u.x; o0.y += u.y; o0.z += u.z; o0.w += u.w;
+        if (lane < 32) {
+          const float4 v = *reinterpret_cast<const float4*>(&red[slot][w][(lane + 64) * 4]);
+          o1.x += v.x; o1.y += v.y; o1.z += v.z; o1.w += v.w;
+        }
+      }
+    }
+    TS_MARK(5);
+    return last;
+  };
+  auto mfma_chain_plain = [&](const unsigned char* sb, f32x16& acc) {
+    constexpr int NB = KB16 / 2;
+    h8 fa[2][2][2];
+    auto fetch = [&](int b, int buf) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[buf][t][0] = *reinterpret_cast<const h8*>(sb + roff(2 * b + t));
+        fa[buf][t][1] = *reinterpret_cast<const h8*>(sb + SL::PIECE + roff(2 * b + t));
+      }
+    };
+    fetch(0, 0); fetch(1, 1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kb = 2 * b + t;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[kb], fa[b & 1][t][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[kb], fa[b & 1][t][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[kb], fa[b & 1][t][0], acc, 0, 0, 0);
+      }
+      if (b + 2 < NB) fetch(b + 2, b & 1);
+    }
+  };
+  // plain consumption (first / last iterations): wait, chain, post
+  auto consume = [&](int64_t i, int slot, uint32_t round, float4& o0, float4& o1) -> bool {
+    if (!consumer || i >= nlocal) return false;
+    const unsigned char* const sb = ring + slot * SL::BYTES;
+    lds_wait_ge(&ready[slot], (uint32_t)NW * (round + 1));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mfma_chain_plain(sb, acc);
+    const float* cf = reinterpret_cast<const float*>(sb + SL::COEF);
+    const float s_row = cf[64 + fr], dom = cf[96 + fr];
+    lds_arrive(&done[slot]);
+    return post(acc, s_row, dom, blockIdx.x + i * (int64_t)gridDim.x, slot, round, o0, o1);
+  };
+  // steady state: the staging steps of tile i + AHEAD ride behind the MFMAs of tile i
+  auto fused = [&](int64_t i, const u32x4 (&rv)[CPT], uint8_t mk, int sslot, uint32_t sround, int cslot, uint32_t cround,
+                   uint32_t pf_done, uint32_t pf_ready, float4& o0, float4& o1) -> bool {
+    TS_MARK(0);
+    lds_wait_ge2(&done[sslot], (uint32_t)NA * sround, pf_done, &ready[cslot], (uint32_t)NW * (cround + 1), pf_ready);
+    TS_MARK(1);
+    unsigned char* const wb = ring + sslot * SL::BYTES;
+    const unsigned char* const sb = ring + cslot * SL::BYTES;
+    StageState q;
+    stage_init(q, rv, mk);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NB = KB16 / 2;
+    h8 fa[2][2][2];
+    auto fetch = [&](int b, int buf) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[buf][t][0] = *reinterpret_cast<const h8*>(sb + roff(2 * b + t));
+        fa[buf][t][1] = *reinterpret_cast<const h8*>(sb + SL::PIECE + roff(2 * b + t));
+      }
+    };
+    fetch(0, 0); fetch(1, 1);
+    const float* cf = reinterpret_cast<const float*>(sb + SL::COEF);
+    const float s_row = cf[64 + fr], dom = cf[96 + fr];
+    int step = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int kb = 2 * b + t;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? wlo[kb] : whi[kb], pr == 0 ? fa[b & 1][t][1] : fa[b & 1][t][0], acc, 0, 0, 0);
+          if (step < STAGE_STEPS) stage_step(q, step, wb);
+          ++step;
+        }
+      }
+      if (b + 2 < NB) fetch(b + 2, b & 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    lds_inc(&ready[sslot]);
+    lds_inc(&done[cslot]);
+    TS_MARK(3);
+    return post(acc, s_row, dom, blockIdx.x + i * (int64_t)gridDim.x, cslot, cround, o0, o1);
+  };
+  // the tile's 32 x 12 floats: item `lane` and item `lane + 64` (16 bytes each); empty descriptor unless this wave finished the tile
+  int64_t st_left = 0;
+  float* st_o = p.raw;
+  auto store_raw = [&](bool live, const float4& o0, const float4& o1) {
+    const int rows_here = (!live || st_left < 0) ? 0 : (st_left > 32 ? 32 : (int)st_left);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(st_o, (short)0, rows_here * R2 * 4, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), ro, lane * 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), ro, (lane + 64) * 16, 0, 0);
+    st_left -= tstep; st_o += tstep * R2;
+  };
+
+  // ---------------------------------------------------------------- pipeline (see transform_stream_kernel)
+  uint32_t pf_done = 0, pf_ready = 0;
+  int ss = 0, cs = 0;
+  uint32_t sr = 0, cr = 0;
+  auto bump = [](int& slot, uint32_t& round) { ++slot; if (slot == SLOTS) { slot = 0; ++round; } };
+  int64_t i_first = -(AHEAD + DEPTH);
+  asm volatile("" : "+s"(i_first));
+  st_left = p.N - ((int64_t)blockIdx.x + i_first * (int64_t)gridDim.x) * 32;
+  st_o = p.raw + ((int64_t)blockIdx.x + i_first * (int64_t)gridDim.x) * 32 * R2;
+  for (int64_t i0 = i_first; i0 < nlocal; i0 += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int64_t i = i0 + u, s = i + AHEAD;
+      u32x4 rv[CPT];
+      uint8_t mk;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned t; asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(ra[u][c][e])); rv[c][e] = t; }
+      }
+      { unsigned tm; asm volatile("v_mov_b32 %0, %1" : "=v"(tm) : "v"((unsigned)rm[u])); mk = (uint8_t)tm; }
+      TS_MARK(0);
+      request(u);
+      TS_MARK(2);
+      float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+      bool live = false;
+      const bool my_turn = (int)(i & 1) == team;                 // (wave-uniform)
+      if (my_turn && i >= 0 && s < nlocal) {
+        live = fused(i, rv, mk, ss, sr, cs, cr, pf_done, pf_ready, o0, o1);
+        bump(ss, sr);
+        bump(cs, cr);
+      } else {
+        if (s >= 0) {
+          stage(s, rv, mk, ss, sr);
+          bump(ss, sr);
+        }
+        if (i >= 0) {
+          if (my_turn) live = consume(i, cs, cr, o0, o1);
+          bump(cs, cr);
+        }
+      }
+      TS_MARK(6);
+      store_raw(live, o0, o1);
+      pf_done = lds_peek(&done[ss]);
+      pf_ready = lds_peek(&ready[cs]);
+      TS_MARK(7);
+    }
+  }
+#ifdef TS_STAMP
+  if (lane == 0 && p.sk_out[0][0] != nullptr) {
+    float* o = p.sk_out[0][0] + ((int64_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) o[k2] = (float)st_acc[k2];
+  }
+#endif
+  // ---------------------------------------------------------------- per-domain column sums of the activation (+ node counts)
+  if (consumer && p.colsum != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float a = cs_s[r], b = cs_t[r];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }     // over the 32 rows of a lane half
+      if (fr == 0) {
+        const int c = col_base + 8 * (r >> 2) + 4 * fh + (r & 3);
+        unsafeAtomicAdd(&p.colsum[c], (double)a);
+        unsafeAtomicAdd(&p.colsum[NC + c], (double)b);
+      }
+    }
+    if (cw == 0) {
+      float a = cnt_s, b = cnt_t;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+      if (lane == 0) { unsafeAtomicAdd(&p.colsum[2 * NC], (double)a); unsafeAtomicAdd(&p.colsum[2 * NC + 1], (double)b); }
+    }
+  }
+}
+
 }  // namespace
 
+static bool stream2_supported(const GemmParams& p);
+
 bool bgnn_tf_stream_supported(const GemmParams& p, int mode) {
+  if (mode == 2) return stream2_supported(p);
   if (mode != 0) return false;
   if (p.n_heads != 1 || p.Din > 128 || p.Din <= 64 || (p.Din & 3) || (p.ldh & 31)) return false;
   if (p.NC != 2 * p.ldh || (p.NC != 256 && p.NC != 128) || p.col_off != 0) return false;
@@ -619,7 +1063,41 @@ bool bgnn_tf_stream_supported(const GemmParams& p, int mode) {
   return true;
 }
 
+static bool stream2_supported(const GemmParams& p) {
+  return p.NC == 128 && p.Din <= 128 && p.Din > 64 && (p.Din & 3) == 0 && p.mask && p.w2 && p.g2 && p.raw && p.ldx * 4 * 32 <= 0x7fffffff;
+}
+
 int bgnn_tf_stream_launch(const GemmParams& p, int mode, hipStream_t st, int n_cu) {
+  if (mode == 2) {
+    if (!stream2_supported(p)) return BGNN_E_SHAPE;
+    const int64_t nt = (p.N + 31) / 32;
+    const dim3 g2((unsigned)(nt < n_cu ? nt : n_cu), 1u);
+#ifdef TS_STAMP
+    {
+      GemmParams q = p;
+      static float* dbuf2 = nullptr;
+      if (!dbuf2) (void)hipMalloc((void**)&dbuf2, sizeof(float) * 256 * 8 * 8);
+      q.sk_out[0][0] = dbuf2;
+      hipLaunchKernelGGL((transform_stream2_kernel<128, 8, 4, TS_SLOTS, TS_AHEAD, TS_DEPTH>), g2, dim3(512), 0, st, q);
+      static int calls2 = 0;
+      if (++calls2 % 12 == 0) {
+        (void)hipDeviceSynchronize();
+        static float host[256 * 8 * 8];
+        (void)hipMemcpy(host, dbuf2, sizeof(float) * g2.x * 8 * 8, hipMemcpyDeviceToHost);
+        double acc[8] = {0};
+        for (unsigned w = 0; w < g2.x * 8; ++w) for (int k = 0; k < 8; ++k) acc[k] += host[w * 8 + k];
+        const double d = (double)g2.x * 8 * ((double)nt / g2.x);
+        fprintf(stderr, "[ts2 stamp] cycles per tile and wave (mean): other %.0f  flags %.0f  request %.0f  chain(+stage, fused turn) %.0f  post %.0f  reduce/flush %.0f  pre-store %.0f  stores+peek %.0f\n",
+                acc[0] / d, acc[1] / d, acc[2] / d, acc[3] / d, acc[4] / d, acc[5] / d, acc[6] / d, acc[7] / d);
+      }
+      BGNN_LAUNCH_CHECK();
+      return 0;
+    }
+#endif
+    hipLaunchKernelGGL((transform_stream2_kernel<128, 8, 4, TS_SLOTS, TS_AHEAD, TS_DEPTH>), g2, dim3(512), 0, st, p);
+    BGNN_LAUNCH_CHECK();
+    return 0;
+  }
   if (!bgnn_tf_stream_supported(p, mode)) return BGNN_E_SHAPE;
   const int64_t ntiles = (p.N + 31) / 32;
   const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu), 1u);

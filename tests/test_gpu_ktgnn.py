@@ -546,3 +546,17 @@ def test_transform_single_table_tail_rows(n_both, n0, n1, din, D):
         t2s_b, s2t_b = conv.transform(x, m8, sums=sums, tail_single=(n0, n1))
     assert torch.equal(t2s_a[:n_both + n0], t2s_b[:n_both + n0])
     assert torch.equal(s2t_a[:n_both], s2t_b[:n_both]) and torch.equal(s2t_a[n_both + n0:], s2t_b[n_both + n0:])
+
+
+def test_stream2_opt_in_kernel_gives_the_same_target_tables():
+    """`transform_stream2_kernel` (the barrier-free pipeline's form of the fused Linear -> narrow transform, BGNN_GEMM_STREAM2=1:
+    opt-in because it measured no faster than the block kernel) is selected through an environment variable read once per
+    process, so the check runs the fused-target test of this file in a child process with the variable set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BGNN_GEMM_STREAM2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k", "fused_transformer_target_tables or ktgnn_office_golden",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -15,7 +15,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-KEEP = ("agg_wide_kernel", "agg_heads", "agg_kernel", "agg_bwd", "gram_", "bn_", "colstats", "transform_bwd", "transform_wreg_kernel", "transform_gemm_kernel", "transform_skinny_kernel",
+KEEP = ("agg_wide_kernel", "agg_heads", "agg_kernel", "agg_bwd", "gram_", "bn_", "colstats", "transform_bwd", "transform_wreg_kernel", "transform_stream", "transform_gemm_kernel", "transform_skinny_kernel",
         "domain_sums_kernel", "cosine_pass1", "knn_", "refine_kernel", "normalize_rows_kernel", "narrow_finish_kernel")
 
 
