@@ -30,6 +30,8 @@ SIGNATURES = {
                                                     _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "bgnn_adaptedconv_transform_need_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P,
                                                     _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "bgnn_classifier_stage_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                          _P, _P, _I32, _INT, _P, _P, _P, _P, _P, _P]),
     "bgnn_linear_narrow_transform_f32": (_INT, [_P, _I64, _I32, _I64, _P, _P, _I32, _INT, _P, _P, _P, _P, _P, _P]),
     "bgnn_narrow_transform_finish_f32": (_INT, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "bgnn_gram_workspace_bytes": (C.c_size_t, [_I32, _I32]),
@@ -91,7 +93,7 @@ def source_hash():
 
 
 # keep in step with HASHED in csrc/Makefile
-_HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_transform_stream.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
+_HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_transform_stream.hip", "bgnn_transform_cls.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
                    "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", "bgnn_transform_params.h", os.path.join("..", "..", "include", "bgnn.h"))
 
 
@@ -104,7 +106,7 @@ def _sidecar_hash():
 
 
 # the ABI revision this binding was written for (include/bgnn.h: BGNN_VERSION); checked against the loaded library
-ABI_VERSION = 111
+ABI_VERSION = 112
 
 
 def _make():

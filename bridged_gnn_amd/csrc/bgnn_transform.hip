@@ -1155,6 +1155,43 @@ extern "C" int bgnn_linear_narrow_transform_f32(const float* x, int64_t N, int32
   return 0;
 }
 
+extern "C" int bgnn_classifier_stage_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                                         const double* sums_x, int32_t sk_heads, int32_t sk_D, const float* sk_Wp,
+                                         const float* sk_bias, const float* sk_gates, const float* sk_gate_const_opt,
+                                         float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1, int64_t sk_ldh,
+                                         int64_t sk_row_stride, const float* W, const float* bias, int32_t Dout, int relu,
+                                         double* colsum, const float* Wp2, const float* gates2, float* raw, float* small_ws,
+                                         void* stream) {
+  if (!x || !mask || !sums_x || !sk_Wp || !sk_bias || !sk_gates || !h_s2t_0 || !h_t2s_0 || !W || !bias || !colsum || !Wp2 || !gates2 ||
+      !raw || !small_ws) return BGNN_E_NULL;
+  if (sk_heads < 1 || sk_heads > MAXH || (sk_heads == 2 && (!h_s2t_1 || !h_t2s_1))) return BGNN_E_NULL;
+  if (N < 0 || Din <= 0 || (Din & 3) || (ldx & 3) || ldx < Din || sk_D <= 0 || sk_ldh < sk_D || (sk_ldh & 3) || (sk_row_stride & 3) ||
+      sk_row_stride < sk_ldh) return BGNN_E_SHAPE;
+  if (!bgnn_aligned16(x) || !bgnn_aligned16(sk_Wp) || !bgnn_aligned16(sk_bias) || !bgnn_aligned16(raw) || !bgnn_aligned16(small_ws))
+    return BGNN_E_ALIGN;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int sk_NC = sk_heads * 2 * (int)sk_ldh;
+  float* wd = small_ws;            // [sk_NC]
+  float* gc = small_ws + sk_NC;    // [sk_heads * 2]
+  GemmParams p{};
+  p.x = x; p.ldx = ldx; p.N = N; p.Din = Din; p.mask = mask; p.Wp = W; p.bias = bias;
+  p.ldh = Dout; p.row_stride = Dout; p.NC = Dout; p.n_heads = 1; p.relu = relu ? 1 : 0; p.colsum = colsum;
+  p.w2 = Wp2; p.g2 = gates2; p.raw = raw;
+  p.sk_Wp = sk_Wp; p.sk_bias = sk_bias; p.sk_wd = wd; p.sk_g = sk_gates; p.sk_gc = gc;
+  p.sk_out[0][0] = h_s2t_0; p.sk_out[0][1] = h_t2s_0; p.sk_out[1][0] = h_s2t_1; p.sk_out[1][1] = h_t2s_1;
+  p.sk_ldh = sk_ldh; p.sk_row_stride = sk_row_stride; p.sk_NC = sk_NC; p.sk_heads = sk_heads;
+  if (!bgnn_tf_cls_supported(p)) return BGNN_E_SHAPE;
+  hipLaunchKernelGGL(wd_kernel, dim3((unsigned)((sk_NC + 2 * sk_heads + 3) / 4)), dim3(256), 0, st, sk_Wp, sk_NC, Din, (const float*)nullptr,
+                     sums_x, sk_gates, sk_gate_const_opt, sk_heads, wd, gc);
+  BGNN_LAUNCH_CHECK();
+  static const int n_cu = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }();
+  return bgnn_tf_cls_launch(p, st, n_cu);
+}
+
 extern "C" int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, const uint8_t* mask, const double* sums,
                                                 int32_t Din, const float* Wp2, const float* bias2, const float* gates2,
                                                 const float* gate_const_opt, float* h_s2t, float* h_t2s,

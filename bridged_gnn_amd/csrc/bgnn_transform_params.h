@@ -52,3 +52,7 @@ __device__ __forceinline__ float tanh_fast(float z) { return 1.f - 2.f * __built
 // Returns 0 when launched, BGNN_E_SHAPE when the shape is outside the kernel's envelope (the caller then takes another kernel).
 int bgnn_tf_stream_launch(const bgnn_tf::GemmParams& p, int mode, hipStream_t st, int n_cu);
 bool bgnn_tf_stream_supported(const bgnn_tf::GemmParams& p, int mode);
+
+// bgnn_transform_cls.hip: the classifier stage's dense work in one pass over h (skinny pair + fused Linear -> narrow stage A)
+int bgnn_tf_cls_launch(const bgnn_tf::GemmParams& p, hipStream_t st, int n_cu);
+bool bgnn_tf_cls_supported(const bgnn_tf::GemmParams& p);

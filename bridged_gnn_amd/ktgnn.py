@@ -748,6 +748,27 @@ class KTGNN_no_complement(nn.Module):
             sums1 = all_reduce(sums1)
         ops.adaptedconv_transform(h1p, mask_u8, None, self._composed_target_pack(h1p.shape[1]), out=[out], sums=sums1)
 
+    def _classifier_stage_fused(self, x, mask_u8, sums_h, views, arena, all_reduce=None):
+        """the three convs' narrow tables from ONE pass over x (bgnn_classifier_stage_f32): clf_base / clf_target on x and stage A of
+        clf_target on clf_transformer(x); stage B after the (optionally all-reduced) sums of the hidden activation.  -> False when the
+        shape is outside the kernel's envelope (the caller then takes the separate launches)."""
+        if sums_h is None or x.dtype != torch.float32 or x.stride(1) != 1:
+            return False
+        self._fold_transformer()
+        dout, din = self._tf_w0.shape
+        if x.shape[1] != din or dout != 128:
+            return False
+        pack_t = self._composed_target_pack(ops.pad4(dout))
+        pair = self.clf_base.packed(x.shape[1], self.clf_target)
+        if not ops.classifier_stage_supported(x, pair, self._tf_w0, pack_t):
+            return False
+        n_s = 2 * ops.pad4(dout) + 2
+        sums_out = arena.take(n_s) if arena is not None else torch.zeros(n_s, dtype=torch.float64, device=x.device)
+        raw = ops.classifier_stage(x, mask_u8, sums_h, pair, [views[0], views[1]], self._tf_w0, self._tf_b0, sums_out, pack_t, relu=True)
+        sums1 = all_reduce(sums_out) if all_reduce is not None else sums_out
+        ops.narrow_transform_finish(raw, mask_u8, sums1, pack_t, views[2])
+        return True
+
     def _composed_target_pack(self, din_pad):
         """clf_target evaluated on x' = h1.W3^T + b3 without materialising x' (the last Linear of clf_transformer is
         affine): W x' + b = (W W3) h1 + (W b3 + b); [x' || d'].g = h1.(W3^T g_x) + b3.g_x + d.(W3^T g_d) with d the
@@ -826,11 +847,12 @@ class KTGNN_no_complement(nn.Module):
             t2s = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
             s2t = torch.empty(N, 3 * ld, dtype=torch.float32, device=x.device)
             views = [(t2s[:, j * ld:(j + 1) * ld], s2t[:, j * ld:(j + 1) * ld]) for j in range(3)]
-            self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
-            # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
-            # h1 = relu(BN(Linear0(x))) is materialised
             arena = self._arena
-            self._transformer_to_target_tables(x, mask_u8, views[2], arena)
+            if not self._classifier_stage_fused(x, mask_u8, sums_h, views, arena):
+                self.clf_base.transform(x, mask_u8, sums=sums_h, partner=self.clf_target, out=[views[0], views[1]])
+                # clf_target(T(x)) (:433): T's last Linear is folded into the conv's packed weights, so only
+                # h1 = relu(BN(Linear0(x))) is materialised
+                self._transformer_to_target_tables(x, mask_u8, views[2], arena)
             akey = (self.clf_base._versions(), self.clf_target._versions())
             if getattr(self, "_a3_key", None) != akey:           # stacked attention vectors, re-packed when a weight changes
                 cs = (self.clf_base, self.clf_target, self.clf_target)

@@ -248,6 +248,39 @@ def linear_narrow_transform(x, weight, bias, mask_u8, colsum, packed, relu=True)
     return raw
 
 
+def classifier_stage_supported(x, packed_pair, weight, packed_t):
+    """envelope of `classifier_stage` (bgnn.h: bgnn_classifier_stage_f32)"""
+    Wp, bp, gates, D, ldh, gconst = packed_pair
+    din = x.shape[1]
+    return (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and 64 < din <= 128 and din % 4 == 0
+            and weight.shape == (128, din) and Wp.shape[0] <= 24 and Wp.shape[1] == din and packed_t[0].shape == (8, 128)
+            and os.environ.get("BGNN_FUSED_CLS", "1") != "0")
+
+
+def classifier_stage(x, mask_u8, sums_x, packed_pair, outs, weight, bias, colsum, packed_t, relu=True):
+    """ONE pass over the hidden activation x for the whole classifier stage's dense work (KTGNN.py:432-434): the narrow
+    (h_t2s, h_s2t) tables of the convs in `packed_pair` (clf_base, clf_target on x; `outs` = list of (h_t2s, h_s2t) views) and
+    stage A of the fused clf_transformer -> clf_target path (`linear_narrow_transform`: -> raw [N, 12], `colsum` += the
+    per-domain column sums of the activation)."""
+    N, din = x.shape
+    Wp, bp, gates, D, ldh, gconst = packed_pair
+    H = gates.shape[0]
+    Wp2, _, gates2, _, _, _ = packed_t
+    raw = torch.empty(N, 12, dtype=torch.float32, device=x.device)
+    small = torch.empty(H * (2 * ldh + 2) + 8, dtype=torch.float32, device=x.device)
+    row_stride = outs[0][0].stride(0)
+    for a, b in outs:
+        assert a.shape[0] >= N and b.shape[0] >= N and a.stride(0) == row_stride and b.stride(0) == row_stride
+    o1 = outs[1] if H > 1 else (None, None)
+    rc = L.lib().bgnn_classifier_stage_f32(L.ptr_rows(x), N, din, x.stride(0), L.ptr(mask_u8), L.ptr(sums_x), H, D, L.ptr(Wp), L.ptr(bp),
+                                           L.ptr(gates), L.ptr(gconst), L.ptr_rows(outs[0][1]), L.ptr_rows(outs[0][0]),
+                                           L.ptr_rows(o1[1]), L.ptr_rows(o1[0]), ldh, row_stride, L.ptr(weight), L.ptr(bias),
+                                           weight.shape[0], 1 if relu else 0, L.ptr(colsum), L.ptr(Wp2), L.ptr(gates2), L.ptr(raw),
+                                           L.ptr(small), L.stream())
+    L.check(rc, "bgnn_classifier_stage_f32")
+    return raw
+
+
 def narrow_transform_finish(raw, mask_u8, sums, packed, out):
     """Stage B: raw [N,12] + the (all-reduced) domain sums of the activation -> the conv's (h_t2s, h_s2t) rows in `out`
     (two [>=N, 4] views with a common row stride)."""

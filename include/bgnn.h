@@ -26,8 +26,8 @@ extern "C" {
 /* ABI revision.  110 (round 3) is NOT call-compatible with 100: `bgnn_transform_bwd_prep_f32` takes 22 arguments (was 17)
  * and the `n_fallback_opt` of `bgnn_cosine_topk_f32` / `bgnn_mlp_pair_topk_f32` is int32[2] (was int32[1]) -- a caller built
  * against the old header must be recompiled; compare bgnn_version() with the BGNN_VERSION it was built with at load time.
- * 111 adds bgnn_adaptedconv_transform_need_f32 (call-compatible with 110). */
-#define BGNN_VERSION 111
+ * 111 adds bgnn_adaptedconv_transform_need_f32, 112 bgnn_classifier_stage_f32 (both call-compatible with 110). */
+#define BGNN_VERSION 112
 #define BGNN_E_NULL (-1)        /* required pointer is NULL                     */
 #define BGNN_E_SHAPE (-2)       /* unsupported / inconsistent shape             */
 #define BGNN_E_WORKSPACE (-3)   /* ws_bytes smaller than *_workspace_bytes()    */
@@ -110,6 +110,18 @@ int bgnn_linear_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const f
 int bgnn_linear_narrow_transform_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const float* W,
                                      const float* bias, int32_t Dout, int relu, const uint8_t* mask,
                                      double* colsum, const float* Wp2, const float* gates2, float* raw, void* stream);
+/* The classifier stage's dense work in ONE pass over the hidden activation x = h (KTGNN.py:432-434; ABI 112): the narrow tables of
+ * the `sk_heads` (1 or 2) convs that read h itself -- the transform of bgnn_adaptedconv_transform_sums_f32 with `sums_x` for the packed
+ * operands sk_Wp / sk_bias / sk_gates (sk_heads * 2 * sk_ldh <= 24 packed columns) -- AND stage A of the fused pair above (W, bias,
+ * Dout = 128, colsum, Wp2, gates2, raw).  Same results as the two separate launches; Din in (64, 128], Din % 4 == 0, else
+ * BGNN_E_SHAPE.  small_ws: sk_heads * (2 * sk_ldh + 2) + 8 floats. */
+int bgnn_classifier_stage_f32(const float* x, int64_t N, int32_t Din, int64_t ldx, const uint8_t* mask,
+                              const double* sums_x, int32_t sk_heads, int32_t sk_D, const float* sk_Wp,
+                              const float* sk_bias, const float* sk_gates, const float* sk_gate_const_opt,
+                              float* h_s2t_0, float* h_t2s_0, float* h_s2t_1, float* h_t2s_1, int64_t sk_ldh,
+                              int64_t sk_row_stride, const float* W, const float* bias, int32_t Dout, int relu,
+                              double* colsum, const float* Wp2, const float* gates2, float* raw, float* small_ws,
+                              void* stream);
 int bgnn_narrow_transform_finish_f32(const float* raw, int64_t N, const uint8_t* mask, const double* sums,
                                      int32_t Din, const float* Wp2, const float* bias2, const float* gates2,
                                      const float* gate_const_opt, float* h_s2t, float* h_t2s, int64_t row_stride,
