@@ -9,7 +9,7 @@
 // holds the tile's fragments in registers (the MFMA B operand, 64 VGPRs) and runs them against FIVE stationary 32-column operands
 // that live in LDS for the whole kernel (the four column tiles of W1' and the skinny tile: 28 rows of narrow weights and gate
 // vectors; 80 KB as fp16 hi / lo pieces, XOR-swizzled like the tiles) -- so the 128 activation columns of a row meet in one wave
-// and the second stage needs no reduction across waves.  One 4-wave block per CU (one wave per SIMD, 150 KB of LDS); the next
+// and the second stage needs no reduction across waves.  One 4-wave block per CU (one wave per SIMD with the whole 512-register budget; 8 waves under 256 registers spilled 205); the next
 // tile's 16 KB of loads are in flight in registers while the current one is worked on.  144 MFMAs per tile and wave
 // (5 x 24 + 4 x 6) are the backbone; the vector work of a column tile's tail (activation, column sums, split, second stage) issues
 // in the gaps of the next tile's chain.
@@ -35,7 +35,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int CLS_TARGET_EXP = 10;
 constexpr int DK = 128, KB16 = DK / 16, NCT = 4;         // four activation column tiles + the skinny tile
 constexpr int PIECE = 32 * DK * 2;                       // one fp16 piece of a 32 x 128 operand: 8 KB
-constexpr int SLOT = 2 * PIECE + 4 * 32 * 4;             // a wave's tile: hi, lo | inverse scales, domain flags, column-sum weights (S, T)
+constexpr int SLOT = 32 * 36 * 4 + 2 * 32 * 4;           // a wave's private LDS: 32 x 32 transpose scratch | column-sum weights of its rows (S, T)
 constexpr int T_LD = 36;                                 // floats per row of the 32 x 32 transpose scratch (inside the slot, once its fragments are in registers)
 
 __device__ __forceinline__ int chunk_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
@@ -46,9 +46,13 @@ __device__ __forceinline__ void pow2_scales(float mx, float& sc, float& inv) {
   inv = __builtin_bit_cast(float, (E - CLS_TARGET_EXP) << 23);
 }
 
-__global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
+constexpr int CLS_NW = 4;                                // waves per block (two per SIMD: one converts / waits while the other feeds the matrix pipe)
+
+__global__ __launch_bounds__(64 * CLS_NW) void cls_stage_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char wl[(NCT + 1) * 2 * PIECE];      // stationary operands [tile][piece][32][128]
-  __shared__ __attribute__((aligned(16))) unsigned char slots[4 * SLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char slots[CLS_NW * SLOT];
+  __shared__ __attribute__((aligned(16))) h8 w2lds[NCT][2][2][64];     // second-stage operand pieces [column tile][k block][hi, lo][lane]
+  __shared__ __attribute__((aligned(16))) float skc[2][32];            // skinny epilogue constants: bias | W.delta of the packed columns
   __shared__ __attribute__((aligned(16))) float bias1[DK];
   __shared__ uint32_t wmax[3];
   __shared__ float red[2][DK + 1];
@@ -57,10 +61,18 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   const int NC = p.NC;                        // = 128
   const bool din_full = p.Din == DK;
+#ifdef CLS_STAMP
+  uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t st_last = 0;
+#define CLS_MARK(k) do { const uint32_t t__ = (uint32_t)__builtin_amdgcn_s_memtime(); st_acc[k] += t__ - st_last; st_last = t__; } while (0)
+#else
+#define CLS_MARK(k) do { } while (0)
+#endif
 
   // ------------------------------------------------------------------ stationary operands -> LDS (all 256 threads, once)
   if (tid < 3) wmax[tid] = 0u;
-  for (int t = tid; t < 2 * (DK + 1); t += 256) (&red[0][0])[t] = 0.f;
+  for (int t = tid; t < 2 * (DK + 1); t += 64 * CLS_NW) (&red[0][0])[t] = 0.f;
+  if (tid < 32) { skc[0][tid] = tid < p.sk_NC ? p.sk_bias[tid] : 0.f; skc[1][tid] = tid < p.sk_NC ? p.sk_wd[tid] : 0.f; }
   if (tid < DK) bias1[tid] = tid < NC ? p.bias[tid] : 0.f;
   __syncthreads();
   // row r of stationary tile ct: W1'[32 ct + r] (ct < 4); skinny tile: packed narrow rows, gate vectors at rows 24..27 and their
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
   };
   // item = (tile, row, 8-float chunk): 5 * 32 * 16 = 2560 items, 10 per thread
   float mx1 = 0.f, mxs = 0.f;
-  for (int it = tid; it < (NCT + 1) * 32 * 16; it += 256) {
+  for (int it = tid; it < (NCT + 1) * 32 * 16; it += 64 * CLS_NW) {
     const int ct = it / 512, r = (it >> 4) & 31, c = it & 15;
     const float* s = src_row(ct, r);
     float m = 0.f;
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
   pow2_scales(__builtin_bit_cast(float, wmax[0]), scW, cinvW);
   pow2_scales(__builtin_bit_cast(float, wmax[1]), scS, cinvS);
   pow2_scales(__builtin_bit_cast(float, wmax[2]), sc2w, cinv2);
-  for (int it = tid; it < (NCT + 1) * 32 * 16; it += 256) {
+  for (int it = tid; it < (NCT + 1) * 32 * 16; it += 64 * CLS_NW) {
     const int ct = it / 512, r = (it >> 4) & 31, c = it & 15;
     const float* s = src_row(ct, r);
     const float sc = ct < NCT ? scW : scS;
@@ -127,32 +139,33 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
     *reinterpret_cast<h8*>(base) = hi;
     *reinterpret_cast<h8*>(base + PIECE) = lo;
   }
-  h8 w2h[NCT][2], w2l[NCT][2];
+  if (wave == 0) {                            // (every wave computed the same values; one writes them)
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+    for (int ct = 0; ct < NCT; ++ct) {
+      h8 hh[2], ll[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const _Float16 h = (_Float16)(w2v[ct][r] * sc2w);
-      w2h[ct][r >> 3][r & 7] = h;
-      w2l[ct][r >> 3][r & 7] = (_Float16)fmaf(w2v[ct][r], sc2w, -(float)h);
+      for (int r = 0; r < 16; ++r) {
+        const _Float16 h = (_Float16)(w2v[ct][r] * sc2w);
+        hh[r >> 3][r & 7] = h;
+        ll[r >> 3][r & 7] = (_Float16)fmaf(w2v[ct][r], sc2w, -(float)h);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) { w2lds[ct][kb][0][lane] = hh[kb]; w2lds[ct][kb][1][lane] = ll[kb]; }
     }
+  }
   __syncthreads();                            // the last block-wide barrier: from here on every wave is on its own
 
   // ------------------------------------------------------------------ skinny epilogue constants (as transform_skinny_kernel):
   // accumulator registers 4q..4q+3 of a lane are packed columns 8q + 4fh + (0..3) of row fr (q < 3); 12..15 the gate products
-  float4 bv[3], wv[3];
   float* optr[3];
   int hsel[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int c = 8 * q + 4 * fh;
-    bv[q] = wv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     optr[q] = nullptr; hsel[q] = 0;
     if (c < p.sk_NC) {
       const int ld2 = 2 * (int)p.sk_ldh;
       const int h = c / ld2, rem = c % ld2, t = rem >= p.sk_ldh ? 1 : 0;
-      bv[q] = *reinterpret_cast<const float4*>(p.sk_bias + c);
-      wv[q] = *reinterpret_cast<const float4*>(p.sk_wd + c);
       float* base = h == 0 ? (t == 0 ? p.sk_out[0][0] : p.sk_out[0][1]) : (t == 0 ? p.sk_out[1][0] : p.sk_out[1][1]);
       optr[q] = base + (rem - t * (int)p.sk_ldh);
       hsel[q] = h * 2 + t;
@@ -164,30 +177,30 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
 
   // ------------------------------------------------------------------ the wave's tiles
   unsigned char* const sb = slots + wave * SLOT;
-  float* const cfs = reinterpret_cast<float*>(sb + 2 * PIECE);          // [0..31] inverse row scales, [32..63] domain flags, [64..95] / [96..127] 1.0 for
-                                                                        // an existing source- / target-domain row (weights of the column sums)
-  float* const tsc = reinterpret_cast<float*>(sb);                     // transpose scratch (the hi piece's space)
-  const int l16 = lane & 15, rsub = lane >> 4;
+  float* const tsc = reinterpret_cast<float*>(sb);                     // transpose scratch
+  float* const cfs = reinterpret_cast<float*>(sb + 32 * T_LD * 4);     // [0..31] / [32..63]: 1.0 for an existing source- / target-domain row
   const int roff0 = chunk_off(fr, fh);
   auto roff = [&](int kb) { return roff0 ^ (kb << 5); };
   const int64_t ntiles = (p.N + 31) / 32;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  float4 ra[8][2];
+  const int64_t stride = (int64_t)gridDim.x * CLS_NW;
+  int64_t tile = (int64_t)blockIdx.x * CLS_NW + wave;
+  // The tile is loaded straight in the MFMA operand layout: lane (fr, fh) takes elements 16kb + 8fh .. +7 (kb < 8) of row fr -- 32
+  // bytes per k block, the two lane halves of a row together one 64-byte segment, so a row's 128-byte lines are fetched once
+  // (the second half hits the L1).  No LDS round trip, no cross-lane reduction beyond one exchange between the two halves.
+  float4 ra[KB16][2];
   uint8_t rmk = 0;
   auto gload = [&](int64_t tl) {              // branch-free: rows past N re-read row N-1 (never stored), chunks past Din chunk 0
+    int64_t r = tl * 32 + fr;
+    r = r < p.N ? r : p.N - 1;
+    const float* src = p.x + r * p.ldx;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      int64_t r = tl * 32 + 4 * g + rsub;
-      r = r < p.N ? r : p.N - 1;
+    for (int kb = 0; kb < KB16; ++kb)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int k = (l16 + 16 * c) * 4;
-        ra[g][c] = *reinterpret_cast<const float4*>(p.x + r * p.ldx + (din_full || k < p.Din ? k : 0));
+        const int k = 16 * kb + 8 * fh + 4 * c;
+        ra[kb][c] = *reinterpret_cast<const float4*>(src + (din_full || k < p.Din ? k : 0));
       }
-    }
-    int64_t r = tl * 32 + fr;
-    rmk = p.mask[r < p.N ? r : p.N - 1];
+    rmk = p.mask[r];
   };
   // column sums of the activation: lane (c = fr, fh) accumulates column 32ct + c over rows 16fh .. 16fh+15 of every tile (the
   // activation tile goes through a 32 x 32 transpose in the slot; per-lane sums of all 16 registers cost 128 VGPRs and spilled)
@@ -197,89 +210,87 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
 
   if (tile < ntiles) gload(tile);
   for (; tile < ntiles; tile += stride) {
-    // ---- (1) the tile leaves the registers as fp16 pieces (row scale, split), the next tile's loads take their place
+    // ---- (1) the tile becomes fp16 fragments in registers (row scale from the row's two lane halves, split); the next tile's loads
+    //          take the place of the fp32 values
+    CLS_MARK(0);
     const bool sdom = rmk != 0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      float f[8];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float4 v = ra[g][c];
-        if (!din_full && (l16 + 16 * c) * 4 >= p.Din) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
-      }
-      float mx = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(fabsf(f[e]), fabsf(f[e + 1])), mx);
-      unsigned b = __builtin_bit_cast(unsigned, mx);
-      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true));
-      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true));
-      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xF, 0xF, true));
-      b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xF, 0xF, true));
-      float sc, inv;
-      pow2_scales(__builtin_bit_cast(float, b), sc, inv);
-      const int row = 4 * g + rsub;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const _Float16 h = (_Float16)(f[4 * c + e] * sc);
-          hi[e] = h;
-          lo[e] = (_Float16)fmaf(f[4 * c + e], sc, -(float)h);
-        }
-        const int c4 = l16 + 16 * c;
-        const int off = chunk_off(row, c4 >> 1) + ((c4 & 1) << 3);
-        *reinterpret_cast<h4*>(sb + off) = hi;
-        *reinterpret_cast<h4*>(sb + PIECE + off) = lo;
-      }
-      if (l16 == 0) cfs[row] = inv;
-    }
-    if (fh == 0) {
-      const bool ex = tile * 32 + fr < p.N;
-      cfs[32 + fr] = sdom ? 1.f : 0.f;
-      cfs[64 + fr] = (ex && sdom) ? 1.f : 0.f;
-      cfs[96 + fr] = (ex && !sdom) ? 1.f : 0.f;
-    }
-    const int64_t tnext = tile + stride < ntiles ? tile + stride : tile;      // past the end: re-read (never staged)
-    gload(tnext);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");           // the wave's own LDS writes before its reads
-    // ---- (2) the tile's fragments (B operand: row fr, k = 16kb + 8fh .. +7) stay in registers for all five operands
-    h8 xh[KB16], xl[KB16];
-#pragma unroll
-    for (int kb = 0; kb < KB16; ++kb) {
-      xh[kb] = *reinterpret_cast<const h8*>(sb + roff(kb));
-      xl[kb] = *reinterpret_cast<const h8*>(sb + PIECE + roff(kb));
-    }
-    const float s_row = cfs[fr], dom = cfs[32 + fr];
     const int64_t row = tile * 32 + fr;
     const bool valid = row < p.N;
-    if (fh == 0) { cnt_s += cfs[64 + fr]; cnt_t += cfs[96 + fr]; }
-    float wsr[16], wtr[16];                   // the weights of this lane's 16 rows (16fh ..) for the column sums
+    float mx = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(&cfs[64 + 16 * fh + 4 * q]);
-      const float4 b = *reinterpret_cast<const float4*>(&cfs[96 + 16 * fh + 4 * q]);
-      wsr[4 * q] = a.x; wsr[4 * q + 1] = a.y; wsr[4 * q + 2] = a.z; wsr[4 * q + 3] = a.w;
-      wtr[4 * q] = b.x; wtr[4 * q + 1] = b.y; wtr[4 * q + 2] = b.z; wtr[4 * q + 3] = b.w;
+    for (int kb = 0; kb < KB16; ++kb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (!din_full && 16 * kb + 8 * fh + 4 * c >= p.Din) ra[kb][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mx = fmaxf(fmaxf(fabsf(ra[kb][c].x), fabsf(ra[kb][c].y)), mx);
+        mx = fmaxf(fmaxf(fabsf(ra[kb][c].z), fabsf(ra[kb][c].w)), mx);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float scx, s_row;
+    pow2_scales(mx, scx, s_row);
+    h8 xh[KB16], xl[KB16];                    // B operand: row fr, k = 16kb + 8fh .. +7, for all five stationary operands
+#pragma unroll
+    for (int kb = 0; kb < KB16; ++kb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float f[4] = {ra[kb][c].x, ra[kb][c].y, ra[kb][c].z, ra[kb][c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const _Float16 h = (_Float16)(f[e] * scx);
+          xh[kb][4 * c + e] = h;
+          xl[kb][4 * c + e] = (_Float16)fmaf(f[e], scx, -(float)h);
+        }
+      }
+    const float dom = sdom ? 1.f : 0.f;
+    if (fh == 0) {
+      cfs[fr] = (valid && sdom) ? 1.f : 0.f;
+      cfs[32 + fr] = (valid && !sdom) ? 1.f : 0.f;
+      cnt_s += (valid && sdom) ? 1.f : 0.f;
+      cnt_t += (valid && !sdom) ? 1.f : 0.f;
     }
-    auto chain = [&](int ct, f32x16& acc) {
-      const unsigned char* wb = wl + (ct * 2) * PIECE;
+    const int64_t tnext = tile + stride < ntiles ? tile + stride : tile;      // past the end: re-read (never used)
+    gload(tnext);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");           // the wave's own LDS writes before its reads
+    // The stationary operand's fragments are requested HALF A CHAIN ahead (two buffers of 4 k blocks = 2 x 32 registers; the
+    // sequence of ten half chains per tile is skinny, tile 0 .. tile 3): left to the compiler every k block was read -> wait ->
+    // 3 MFMAs through one register pair, i.e. 40 exposed LDS round trips per tile with nothing else on the SIMD to cover them.
+    constexpr int HK = KB16 / 2;
+    h8 wf[2][HK][2];
+    auto fetch_w = [&](int hc, int buf) {     // half chain hc = 2 * operand + half; operand 0 = skinny tile (LDS tile NCT), 1.. = tiles 0..
+      const int op = hc >> 1, half = hc & 1;
+      const unsigned char* wb = wl + ((op == 0 ? NCT : op - 1) * 2) * PIECE;
 #pragma unroll
-      for (int kb = 0; kb < KB16; ++kb) {
-        const h8 wh = *reinterpret_cast<const h8*>(wb + roff(kb));
-        const h8 wlo = *reinterpret_cast<const h8*>(wb + PIECE + roff(kb));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[kb], acc, 0, 0, 0);      // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh[kb], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[kb], acc, 0, 0, 0);
+      for (int j = 0; j < HK; ++j) {
+        wf[buf][j][0] = *reinterpret_cast<const h8*>(wb + roff(HK * half + j));
+        wf[buf][j][1] = *reinterpret_cast<const h8*>(wb + PIECE + roff(HK * half + j));
       }
     };
+    // `between(kb)`: vector work dropped behind the three MFMAs of k block kb (the second stage of the PREVIOUS column tile: with one
+    // wave per SIMD nothing else fills the chain's issue gaps)
+    auto half_chain = [&](int hc, f32x16& acc, auto&& between) {          // prefetches half chain hc + 1, runs half chain hc (buffer hc & 1)
+      if (hc + 1 < 2 * (NCT + 1)) fetch_w(hc + 1, (hc + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int half = hc & 1, buf = hc & 1;
+#pragma unroll
+      for (int j = 0; j < HK; ++j) {
+        const int kb = HK * half + j;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][j][0], xl[kb], acc, 0, 0, 0);      // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][j][1], xh[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][j][0], xh[kb], acc, 0, 0, 0);
+        between(kb);
+      }
+    };
+    auto nothing = [](int) {};
+    CLS_MARK(1);                              // convert (+ wait for the tile's loads)
+    fetch_w(0, 0);
     // ---- (3) the skinny tile (needs only the fragment registers; the slot becomes scratch afterwards): narrow tables of the two convs on h itself (KTGNN.py:277-284 by linearity, see bgnn_transform.hip)
-    if (p.sk_NC > 0) {
+    {                                         // (without a skinny operand its LDS tile is zero and nothing is stored)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      chain(NCT, acc);
+      half_chain(0, acc, nothing);
+      half_chain(1, acc, nothing);
+      CLS_MARK(2);                            // skinny chain
       const float ss = s_row * cinvS;
       if (valid) {
         float cf = 0.f;
@@ -293,9 +304,10 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
               cf = ((dom != 0.f) != t1) ? tanh_fast(fmaf(pre, ss, gcv)) : 0.f;
               cf = t1 ? cf : -cf;
             }
+            const float4 bq = *reinterpret_cast<const float4*>(&skc[0][8 * q + 4 * fh]), wq = *reinterpret_cast<const float4*>(&skc[1][8 * q + 4 * fh]);
             float4 o;
-            o.x = fmaf(cf, wv[q].x, fmaf(acc[4 * q], ss, bv[q].x));     o.y = fmaf(cf, wv[q].y, fmaf(acc[4 * q + 1], ss, bv[q].y));
-            o.z = fmaf(cf, wv[q].z, fmaf(acc[4 * q + 2], ss, bv[q].z)); o.w = fmaf(cf, wv[q].w, fmaf(acc[4 * q + 3], ss, bv[q].w));
+            o.x = fmaf(cf, wq.x, fmaf(acc[4 * q], ss, bq.x));     o.y = fmaf(cf, wq.y, fmaf(acc[4 * q + 1], ss, bq.y));
+            o.z = fmaf(cf, wq.z, fmaf(acc[4 * q + 2], ss, bq.z)); o.w = fmaf(cf, wq.w, fmaf(acc[4 * q + 3], ss, bq.w));
             *reinterpret_cast<float4*>(optr[q] + row * p.sk_row_stride) = o;
           }
         }
@@ -306,58 +318,85 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o2[i] = 0.f;
     const float sc1 = s_row * cinvW;
+    // second stage of a column tile, in eight steps (one per k block of the NEXT tile's chain): row scale of the activation ->
+    // fp16 pieces -> 6 MFMAs against the tile's slice of (w2 | g2) -> the 12 per-row products; column sums from the transposed tile
+    struct Stage2 { float a1[16]; float mx, sc2, inv2; h8 ah[2], al[2]; f32x16 acc2; h8 w2h[2], w2l[2]; };
+    auto stage2_step = [&](Stage2& q, int ct, int j) {
+      if (j == 0) {
+        q.mx = fmaxf(q.mx, __shfl_xor(q.mx, 32));          // the row's two lane halves share the scale
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { q.w2h[kb] = w2lds[ct][kb][0][lane]; q.w2l[kb] = w2lds[ct][kb][1][lane]; }
+      } else if (j == 1) {
+        pow2_scales(q.mx, q.sc2, q.inv2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q.acc2[r] = 0.f;
+      } else if (j == 2 || j == 3) {
+        const int kb = j - 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const _Float16 h = (_Float16)(q.a1[8 * kb + e] * q.sc2);
+          q.ah[kb][e] = h;
+          q.al[kb][e] = (_Float16)fmaf(q.a1[8 * kb + e], q.sc2, -(float)h);
+        }
+      } else if (j == 4 || j == 5) {
+        const int kb = j - 4;
+        q.acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q.w2h[kb], q.al[kb], q.acc2, 0, 0, 0);
+        q.acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q.w2l[kb], q.ah[kb], q.acc2, 0, 0, 0);
+        q.acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q.w2h[kb], q.ah[kb], q.acc2, 0, 0, 0);
+      } else if (j == 6) {
+        // column sums: this lane's column of the transposed tile, its 16 rows (written by this wave before the chain started)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = tsc[(16 * fh + r) * T_LD + fr];
+          cs_s[ct] = fmaf(cfs[16 * fh + r], v, cs_s[ct]);  // (weights of the lane's 16 rows: LDS broadcasts, no registers held)
+          cs_t[ct] = fmaf(cfs[32 + 16 * fh + r], v, cs_t[ct]);
+        }
+      } else {
+        const float s2 = q.inv2 * cinv2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o2[i] = fmaf(q.acc2[i], s2, o2[i]);
+      }
+    };
+    Stage2 q2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    CLS_MARK(3);                              // skinny epilogue
+    half_chain(2, acc, nothing);
+    half_chain(3, acc, nothing);
+    CLS_MARK(4);                              // first activation chain (nothing behind it)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      f32x16 acc;
+      // activation of column tile ct from its finished accumulators; the tile also goes (transposed) through the scratch
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");          // the previous tile's column-sum reads are done
+      q2.mx = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      chain(ct, acc);
-      float a1[16];
-      float mx = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&bias1[32 * ct + 8 * q + 4 * fh]);
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&bias1[32 * ct + 8 * qq + 4 * fh]);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = fmaf(acc[4 * q + e], sc1, bb[e]);
+          float v = fmaf(acc[4 * qq + e], sc1, bb[e]);
           if (p.relu) v = fmaxf(v, 0.f);
-          a1[4 * q + e] = v;
-          mx = fmaxf(mx, fabsf(v));
+          q2.a1[4 * qq + e] = v;
+          q2.mx = fmaxf(q2.mx, fabsf(v));
         }
-        *reinterpret_cast<float4*>(&tsc[fr * T_LD + 8 * q + 4 * fh]) = make_float4(a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]);
+        *reinterpret_cast<float4*>(&tsc[fr * T_LD + 8 * qq + 4 * fh]) =
+            make_float4(q2.a1[4 * qq], q2.a1[4 * qq + 1], q2.a1[4 * qq + 2], q2.a1[4 * qq + 3]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));                  // the row's two lane halves share the scale
-      float sc2, inv2;
-      pow2_scales(mx, sc2, inv2);
-      h8 ah[2], al[2];
+      CLS_MARK(5);                            // activation + transpose writes
+      if (ct + 1 < NCT) {
+        // the next column tile's chain, the second stage of THIS tile behind its MFMAs
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const _Float16 h = (_Float16)(a1[r] * sc2);
-        ah[r >> 3][r & 7] = h;
-        al[r >> 3][r & 7] = (_Float16)fmaf(a1[r], sc2, -(float)h);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        half_chain(2 * (ct + 2), acc, [&](int kb) { stage2_step(q2, ct, kb); });
+        half_chain(2 * (ct + 2) + 1, acc, [&](int kb) { stage2_step(q2, ct, kb); });
+        CLS_MARK(6);                          // chain with the second stage behind it
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage2_step(q2, ct, j);
+        CLS_MARK(7);                          // last second stage (exposed)
       }
-      f32x16 acc2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[ct][kb], al[kb], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[ct][kb], ah[kb], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[ct][kb], ah[kb], acc2, 0, 0, 0);
-      }
-      const float s2 = inv2 * cinv2;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o2[i] = fmaf(acc2[i], s2, o2[i]);
-      // column sums: this lane's column of the transposed tile, its 16 rows (the wave's own writes: in-order LDS queue)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float v = tsc[(16 * fh + j) * T_LD + fr];
-        cs_s[ct] = fmaf(wsr[j], v, cs_s[ct]);
-        cs_t[ct] = fmaf(wtr[j], v, cs_t[ct]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");          // reads done before the next column tile overwrites the scratch
     }
     // accumulator register i of lane (fr, fh) is output 8*(i/4) + 4*fh + i%4 of row fr: lane half 0 holds outputs 0..3 and
     // 8..11 (8, 9 are the gate products), lane half 1 outputs 4..7
@@ -371,6 +410,13 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
       }
     }
   }
+#ifdef CLS_STAMP
+  if (lane == 0 && p.wd != nullptr) {          // (p.wd is not used by this kernel: the stamped build borrows it for its debug buffer)
+    float* o = const_cast<float*>(p.wd) + ((int64_t)blockIdx.x * CLS_NW + wave) * 8;
+    for (int k = 0; k < 8; ++k) o[k] = (float)st_acc[k];
+  }
+  return;
+#endif
   // ------------------------------------------------------------------ per-domain column sums of the activation (+ node counts):
   // lanes -> wave (xor butterfly over the 32 rows of a lane half) -> block (LDS float adds) -> one fp64 atomic per (block, column, domain)
   if (p.colsum != nullptr) {
@@ -389,7 +435,7 @@ __global__ __launch_bounds__(256) void cls_stage_kernel(GemmParams p) {
       if (lane == 0) { unsafeAtomicAdd(&red[0][DK], a); unsafeAtomicAdd(&red[1][DK], b); }
     }
     __syncthreads();
-    for (int t = tid; t < 2 * (DK + 1); t += 256) {
+    for (int t = tid; t < 2 * (DK + 1); t += 64 * CLS_NW) {
       const int d = t / (DK + 1), c = t % (DK + 1);
       const double v = (double)red[d][c];
       if (c == DK) unsafeAtomicAdd(&p.colsum[2 * NC + d], v);
@@ -409,8 +455,27 @@ bool bgnn_tf_cls_supported(const GemmParams& p) {
 
 int bgnn_tf_cls_launch(const GemmParams& p, hipStream_t st, int n_cu) {
   if (!bgnn_tf_cls_supported(p)) return BGNN_E_SHAPE;
-  const int64_t nt = (p.N + 31) / 32, nb = (nt + 3) / 4;
-  hipLaunchKernelGGL(cls_stage_kernel, dim3((unsigned)(nb < n_cu ? nb : n_cu)), dim3(256), 0, st, p);
+  const int64_t nt = (p.N + 31) / 32, nb = (nt + CLS_NW - 1) / CLS_NW;
+#ifdef CLS_STAMP
+  {
+    GemmParams q = p;
+    static float* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc((void**)&dbuf, sizeof(float) * 256 * 8 * 8);
+    q.wd = dbuf;
+    const unsigned g = (unsigned)(nb < n_cu ? nb : n_cu);
+    hipLaunchKernelGGL(cls_stage_kernel, dim3(g), dim3(64 * CLS_NW), 0, st, q);
+    (void)hipDeviceSynchronize();
+    static float host[256 * 8 * 8];
+    (void)hipMemcpy(host, dbuf, sizeof(float) * g * CLS_NW * 8, hipMemcpyDeviceToHost);
+    double acc[8] = {0};
+    for (unsigned w = 0; w < g * CLS_NW; ++w) for (int k = 0; k < 8; ++k) acc[k] += host[w * 8 + k];
+    const double d = (double)nt;
+    fprintf(stderr, "[cls stamp] cycles per tile: loop %.0f convert %.0f skinny-chain %.0f skinny-epilogue %.0f first-chain %.0f activation(x4) %.0f chain+stage2(x3) %.0f last-stage2 %.0f\n",
+            acc[0] / d, acc[1] / d, acc[2] / d, acc[3] / d, acc[4] / d, acc[5] / d, acc[6] / d, acc[7] / d);
+    return 0;
+  }
+#endif
+  hipLaunchKernelGGL(cls_stage_kernel, dim3((unsigned)(nb < n_cu ? nb : n_cu)), dim3(64 * CLS_NW), 0, st, p);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
