@@ -66,6 +66,9 @@ struct AggParams {
   int64_t n_vrows;
   float* vout; float* vms;
   int32_t hub_threshold;
+  // agg_wide_fast_kernel only (filled by fast_plan): both tables inside ONE window of < 4 GB, addressed by 32-bit byte offsets
+  const char* tbl_base;
+  uint32_t tbl_bytes, off_t2s, off_s2t;
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -578,6 +581,224 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   }
 }
 
+// ---- wide rows, the plain launch (heads == 1, mode 0, no hub segments, no alpha) with 32-bit addressing ------------------------
+// agg_wide_kernel is VALU-bound on gfx950 (PMC, C4: VALU busy 78 % of the launch, 440 M wave instructions: ~105 per step of
+// U = 4 edges x 2 rows plus ~230 per row pair of set-up / epilogue), not gather-bound.  This variant drops what the plain
+// launch does not need, in the SAME arithmetic order (results are bit-identical to agg_wide_kernel, tests pin that):
+//  * addresses: both tables lie in one window of < 4 GB (fast_plan checks), so a neighbour row is `window + 32-bit byte
+//    offset` through ONE buffer descriptor.  The lane that owns a slot multiplies its id once (v_mul_u32_u24) and the
+//    four gathers of a step take their offset as `lane base + quad-broadcast(offset)`, one v_add_u32 with a DPP operand
+//    each -- instead of per edge: a DPP move, a clamp and a quarter-rate v_mad_u64_u32 (4 issue slots);
+//  * a slot past the row's end carries offset 0 and a `valid` bit instead of id -1 + clamp;
+//  * row set-up in 32-bit integers, no (row, head) division, no virtual-row / two-part / alpha branches;
+//  * the per-domain column sums take the row with weight 1 / 0 (packed FMAs) instead of two divergent branches.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_movu(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true); }
+
+template <int LF>
+__global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
+  static_assert(LF == 16 || LF == 32 || LF == 64, "wide rows only");
+  constexpr int U = 4;
+  constexpr int GPW = 64 / LF;
+  constexpr int RPB = 4 * GPW;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / LF;
+  const int lg = lane % LF;
+  const int f0 = lg * 4;
+  const bool fvalid = f0 < p.D;
+  const int f0c = fvalid ? f0 : 0;
+  const int k = lane & (U - 1);
+  const bool b0 = lane & 1, b1 = lane & 2;
+
+  const int32_t row0 = (int32_t)p.row_begin, row1 = (int32_t)p.row_end;
+  const int32_t ntiles = (row1 - row0 + RPB - 1) / RPB;
+  __shared__ float red[2][LF * 4 + 1];
+  if (p.colsum != nullptr) {
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) (&red[0][0])[t] = 0.f;
+    __syncthreads();
+  }
+  __shared__ unsigned int dyn_tile;
+  const uint32_t nstride = (uint32_t)(p.ldh * 4);
+  const uint32_t ostride = (uint32_t)(p.ldo * 4);
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.tbl_base), (short)0, (int)p.tbl_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, (short)0, (int)((uint32_t)row1 * ostride), 0x00020000);
+  const f2 sl = {p.slope, p.slope};
+  float sc4[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.ep_scale != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (f0 + c < p.D) { sc4[c] = p.ep_scale[f0 + c]; sh4[c] = p.ep_shift[f0 + c]; }
+  }
+  f2 cs_s01 = {0.f, 0.f}, cs_s23 = cs_s01, cs_t01 = cs_s01, cs_t23 = cs_s01;   // column sums of the rows this lane wrote, per domain
+  float n_s = 0.f, n_t = 0.f;
+  f2 aS01 = {0.f, 0.f}, aS23 = aS01, aT01 = aS01, aT23 = aS01;
+  if (fvalid) {
+    aS01.x = p.a_t2s[f0]; aS01.y = f0 + 1 < p.D ? p.a_t2s[f0 + 1] : 0.f;
+    aS23.x = f0 + 2 < p.D ? p.a_t2s[f0 + 2] : 0.f; aS23.y = f0 + 3 < p.D ? p.a_t2s[f0 + 3] : 0.f;
+    aT01.x = p.a_s2t[f0]; aT01.y = f0 + 1 < p.D ? p.a_s2t[f0 + 1] : 0.f;
+    aT23.x = f0 + 2 < p.D ? p.a_s2t[f0 + 2] : 0.f; aT23.y = f0 + 3 < p.D ? p.a_s2t[f0 + 3] : 0.f;
+  }
+  // tile scheduling: agg_wide_kernel's (per-XCD queue, interleaved claims, XCD segments), in 32-bit integers
+  const int32_t TQ_CHUNK = p.tq_chunk;
+  const int32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int32_t G = ((int32_t)gridDim.x + 7 - xcd) / 8;           // blocks on this XCD
+  const int32_t tstride = p.tq_interleave ? G : 1;
+  const int32_t NSEG = p.xcd_segments > 1 ? p.xcd_segments : 1;
+  const int32_t per_x = (ntiles + 7) / 8, seg_len = (per_x + NSEG - 1) / NSEG;
+  const int32_t xbase = xcd * per_x;
+  const int32_t xend = NSEG > 1 ? xbase + NSEG * seg_len : min((xcd + 1) * per_x, ntiles);
+  int32_t tile = xbase + slot - G;
+  int32_t chunk_left = 0;
+  for (;;) {
+    if (p.tile_queue != nullptr) {
+      if (chunk_left == 0) {                     // block-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) dyn_tile = atomicAdd(&p.tile_queue[xcd], 1u);
+        __syncthreads();
+        const uint32_t kq = dyn_tile;
+        if (p.tq_interleave) {
+          const int32_t sc = (int32_t)kq / G, r = (int32_t)kq - sc * G;
+          tile = xbase + sc * (TQ_CHUNK * G) + r;
+        } else {
+          tile = xbase + (int32_t)kq * TQ_CHUNK;
+        }
+        chunk_left = TQ_CHUNK;
+        if (tile >= xend) break;
+      } else {
+        tile += tstride;
+      }
+      --chunk_left;
+      if (tile >= xend) { chunk_left = 0; continue; }
+    } else {
+      tile += G;
+      if (tile >= xend) break;
+    }
+    int32_t gt = tile;
+    if (NSEG > 1) {
+      const int32_t j = tile - xbase, sg = j / seg_len;
+      gt = (sg * 8 + xcd) * seg_len + (j - sg * seg_len);
+      if (gt >= ntiles) continue;                // padding of the last segments (block-uniform)
+    }
+    const int32_t i0 = row0 + gt * RPB + wave * GPW + g;
+    const bool rvalid = i0 < row1;
+    const int32_t ic = rvalid ? i0 : row0;
+    const bool dom_s = p.mask[ic] != 0;
+    const int32_t beg = rvalid ? p.rowptr[ic] : 0;
+    const int32_t end = rvalid ? p.rowptr[ic + 1] : 0;
+    const uint32_t lbase = (dom_s ? p.off_t2s : p.off_s2t) + (uint32_t)f0c * 4u;     // this lane's columns of row 0 of its table
+    const f2 a01 = dom_s ? aS01 : aT01, a23 = dom_s ? aS23 : aT23;
+    const float4 hi4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + __umul24((uint32_t)ic, nstride), 0, 0));
+    const f2 h01 = {hi4.x, hi4.y}, h23 = {hi4.z, hi4.w};
+
+    float m = -INFINITY, s = 0.f;          // s: per-lane partial (sum over the steps of "my" edge slot)
+    f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    const int32_t niter = (end - beg + U - 1) / U;
+    int32_t e = beg + k;
+    bool ok = e < end;
+    uint32_t myoff = 0;                    // byte offset of my slot's neighbour row inside its table
+    if (niter > 0) myoff = __umul24((uint32_t)p.col[min(e, end - 1)], nstride);
+    for (int32_t it = 0; it < niter; ++it) {
+      float4 v[U];
+      v[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x00>(myoff), 0, 0));
+      v[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x55>(myoff), 0, 0));
+      v[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xAA>(myoff), 0, 0));
+      v[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xFF>(myoff), 0, 0));
+      // next step's id: an UNCONDITIONAL load (a slot past the end re-reads the row's last id and is dead by `ok`): behind a
+      // branch the compiler waits for it -- and for the four gathers issued before it -- inside the branch
+      const int32_t e2 = e + U;
+      const bool ok2 = e2 < end;
+      // Issued HERE, behind the gathers, as inline assembly: written as `p.col[..]` the compiler sinks the load (its only use is the
+      // next iteration's offset) to the loop top, where the gathers then wait for it -- two dependent round trips per step.  The
+      // compiler does not count this load in its s_waitcnt vmcnt(n): it then waits for one load more than it needs, never less
+      // (loads return in order); the value itself is taken behind the explicit wait at the end of the step.
+      uint32_t nextid;
+      const uint32_t e2off = (uint32_t)min(e2, end - 1) * 4u;
+      __builtin_amdgcn_sched_barrier(0);           // the four gathers and this load go out back to back, nothing scheduled between them
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(nextid) : "v"(e2off), "s"(p.col) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+
+      float t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        f2 z0 = f2{v[u].x, v[u].y} + h01, z1 = f2{v[u].z, v[u].w} + h23;
+        z0 = __builtin_elementwise_max(z0, z0 * sl);
+        z1 = __builtin_elementwise_max(z1, z1 * sl);
+        f2 q = a01 * z0;
+        q = __builtin_elementwise_fma(a23, z1, q);
+        t[u] = q.x + q.y;
+      }
+      const float rA = bfly<0xB1>(b0, t[0], t[1]), rB = bfly<0xB1>(b0, t[2], t[3]);
+      float r = bfly<0x4E>(b1, rA, rB);
+      r += bgnn::dpp_mov<0x124>(r);                         // row_ror:4 (keeps lane & 3)
+      r += bgnn::dpp_mov<0x128>(r);                         // row_ror:8
+      if constexpr (LF >= 32) r += bgnn::swz_xor16(r);
+      if constexpr (LF >= 64) r += __shfl_xor(r, 32);
+      const float l = ok ? r : -INFINITY;
+      float cm = fmaxf(l, bgnn::dpp_mov<0xB1>(l));
+      cm = fmaxf(cm, bgnn::dpp_mov<0x4E>(cm));
+      const float mn = fmaxf(m, cm);
+      const float sc = (m == mn) ? 1.f : __expf(m - mn);
+      const float pe = (l == -INFINITY) ? 0.f : __expf(l - mn);
+      s = fmaf(s, sc, pe);
+      const f2 sc2 = {sc, sc};
+      acc01 *= sc2; acc23 *= sc2;
+#define BGNN_ACC(u, w)                                               \
+      {                                                              \
+        acc01.x = fmaf(w, v[u].x, acc01.x); acc01.y = fmaf(w, v[u].y, acc01.y); \
+        acc23.x = fmaf(w, v[u].z, acc23.x); acc23.y = fmaf(w, v[u].w, acc23.y); \
+      }
+      { const float w = quad_bcast<0>(pe); BGNN_ACC(0, w) }
+      { const float w = quad_bcast<1>(pe); BGNN_ACC(1, w) }
+      { const float w = quad_bcast<2>(pe); BGNN_ACC(2, w) }
+      { const float w = quad_bcast<3>(pe); BGNN_ACC(3, w) }
+#undef BGNN_ACC
+      m = mn;
+      e = e2; ok = ok2;
+      __builtin_amdgcn_sched_barrier(0);           // (the wait stays behind the step's arithmetic)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nextid) : : "memory");
+      myoff = __umul24(nextid, nstride);
+    }
+    s += bgnn::dpp_mov<0xB1>(s);
+    s += bgnn::dpp_mov<0x4E>(s);
+
+    const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
+    if (rvalid && f0 < p.ldo) {
+      float4 o = make_float4(acc01.x * inv, acc01.y * inv, acc23.x * inv, acc23.y * inv);
+      if (p.ep_scale != nullptr) {
+        o.x = fmaf(o.x, sc4[0], sh4[0]); o.y = fmaf(o.y, sc4[1], sh4[1]);
+        o.z = fmaf(o.z, sc4[2], sh4[2]); o.w = fmaf(o.w, sc4[3], sh4[3]);
+      }
+      if (p.ep_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (!fvalid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), ro, __umul24((uint32_t)i0, ostride) + (uint32_t)f0 * 4u, 0, 0);
+      if (p.colsum != nullptr) {            // weight 1 / 0 per domain: o * 1 + cs == cs + o, o * 0 + cs == cs (finite o)
+        const float ws = dom_s ? 1.f : 0.f, wt = dom_s ? 0.f : 1.f;
+        const f2 ws2 = {ws, ws}, wt2 = {wt, wt}, o01 = {o.x, o.y}, o23 = {o.z, o.w};
+        cs_s01 = __builtin_elementwise_fma(o01, ws2, cs_s01); cs_s23 = __builtin_elementwise_fma(o23, ws2, cs_s23);
+        cs_t01 = __builtin_elementwise_fma(o01, wt2, cs_t01); cs_t23 = __builtin_elementwise_fma(o23, wt2, cs_t23);
+        n_s += ws; n_t += wt;
+      }
+    }
+  }
+  if (p.colsum != nullptr) {
+    unsafeAtomicAdd(&red[0][f0], cs_s01.x); unsafeAtomicAdd(&red[0][f0 + 1], cs_s01.y);
+    unsafeAtomicAdd(&red[0][f0 + 2], cs_s23.x); unsafeAtomicAdd(&red[0][f0 + 3], cs_s23.y);
+    unsafeAtomicAdd(&red[1][f0], cs_t01.x); unsafeAtomicAdd(&red[1][f0 + 1], cs_t01.y);
+    unsafeAtomicAdd(&red[1][f0 + 2], cs_t23.x); unsafeAtomicAdd(&red[1][f0 + 3], cs_t23.y);
+    if (lg == 0) { unsafeAtomicAdd(&red[0][LF * 4], n_s); unsafeAtomicAdd(&red[1][LF * 4], n_t); }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * (LF * 4 + 1); t += 256) {
+      const int d = t / (LF * 4 + 1), c = t % (LF * 4 + 1);
+      const double sum = (double)red[d][c];
+      if (c == LF * 4) unsafeAtomicAdd(&p.colsum[2 * p.ldo + d], sum);
+      else if (c < p.ldo) unsafeAtomicAdd(&p.colsum[d * p.ldo + c], sum);
+    }
+  }
+}
+
 // Narrow multi-head variant (D <= 4, i.e. one float4 per head): ONE walk of a destination's in-edges serves all HEADS convs
 // (KT-GNN's classifier stage: clf_base(x), clf_target(x), clf_target(T(x)) share the graph; tables interleaved per node).
 // One lane per (edge slot, head): lanes lg = sub * HEADS + h of a row's group.  The HEADS lanes of an edge read the
@@ -798,6 +1019,53 @@ int launch_wide(const AggParams& p, hipStream_t st) {
   return 0;
 }
 
+// Can this launch run agg_wide_fast_kernel?  table_rows = rows of the two tables (every id in `col` is below it; 0 = unknown).
+// Fills the window fields of `p`.  BGNN_AGG_FAST=0 keeps the general kernel (tests compare the two bit for bit).
+static bool fast_plan(AggParams& p, int64_t table_rows) {
+  static const bool on = [] { const char* e = getenv("BGNN_AGG_FAST"); return !(e && atoi(e) == 0); }();
+  if (!on || table_rows <= 0) return false;
+  if (p.heads != 1 || p.mode != 0 || p.alpha != nullptr || p.n_vrows != 0 || p.hub_threshold != 0) return false;
+  const int64_t lim24 = (int64_t)1 << 24, lim32 = ((int64_t)1 << 32) - 1;       // v_mul_u32_u24 operands / 32-bit byte offsets
+  if (table_rows > lim24 || p.row_end > table_rows || p.ldh * 4 >= lim24 || p.ldo * 4 >= lim24) return false;
+  const char* a = reinterpret_cast<const char*>(p.h_t2s);
+  const char* b = reinterpret_cast<const char*>(p.h_s2t);
+  const char* lo = a < b ? a : b;
+  const int64_t span = (int64_t)((a < b ? b : a) - lo) + table_rows * p.ldh * 4;
+  if (span > lim32 || p.row_end * p.ldo * 4 > lim32) return false;
+  p.tbl_base = lo;
+  p.tbl_bytes = (uint32_t)span;
+  p.off_t2s = (uint32_t)(a - lo);
+  p.off_s2t = (uint32_t)(b - lo);
+  return true;
+}
+
+template <int LF>
+int launch_wide_fast(const AggParams& p, hipStream_t st) {
+  constexpr int RPB = 4 * (64 / LF);
+  static const int cap = [] {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_fast_kernel<LF>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+    if (per_cu > 8) per_cu = 8;
+    const char* e = getenv("BGNN_AGG_BLOCKS_PER_CU");
+    if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
+    return per_cu * prop.multiProcessorCount / 8 * 8;
+  }();
+  const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
+  int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
+  if (grid < 8) grid = 8;
+  AggParams q = p;
+  q.tq_chunk = tq_chunk_for(ntiles, grid);
+  static const int il = [] { const char* e = getenv("BGNN_AGG_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  q.tq_interleave = il;
+  static const int nseg = [] { const char* e = getenv("BGNN_XCD_SEGMENTS"); return e ? atoi(e) : 8; }();
+  q.xcd_segments = nseg;
+  hipLaunchKernelGGL((agg_wide_fast_kernel<LF>), dim3((unsigned)grid), dim3(256), 0, st, q);
+  BGNN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- hub rows: merge of the parked segment states (see AggParams::hub_threshold) -------------------------------------------
 struct HubMergeParams {
   const int32_t* hub_rows; const int32_t* seg_ptr; int64_t n_hubs;
@@ -933,7 +1201,7 @@ __global__ __launch_bounds__(256) void hub_merge_heads_kernel(HubMergeParams p) 
   *reinterpret_cast<float4*>(p.out + (node * p.heads + h) * p.ldo) = r;
 }
 
-static int dispatch_aggregate(const AggParams& p, hipStream_t st) {
+static int dispatch_aggregate(const AggParams& p, hipStream_t st, int64_t table_rows = 0) {
   const int32_t D = p.D, heads = p.heads;
   if (heads == 3 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<3, 2, 4>(p, st);   // KT-GNN's classifier stage
   if (heads == 2 && D <= 4 && p.ldh == 4 && p.ldo == 4) return launch_heads<2, 2, 4>(p, st);
@@ -947,6 +1215,12 @@ static int dispatch_aggregate(const AggParams& p, hipStream_t st) {
   // wide rows: the VALU-lean kernel (needs max(z, slope*z) == leaky_relu and 32-bit row strides)
   const bool wide_ok = p.slope >= 0.f && p.slope <= 1.f && (int64_t)heads * p.ldh * 4 < (int64_t)1 << 32;
   if (wide_ok) {
+    AggParams q = p;
+    if (fast_plan(q, table_rows)) {
+      if (nv <= 16) return launch_wide_fast<16>(q, st);
+      if (nv <= 32) return launch_wide_fast<32>(q, st);
+      return launch_wide_fast<64>(q, st);
+    }
     if (nv <= 16) return launch_wide<16, 4>(p, st);
     if (nv <= 32) return launch_wide<32, 4>(p, st);
     return launch_wide<64, 4>(p, st);
@@ -965,14 +1239,14 @@ static bool hub_capable(int32_t D, int64_t ldh, int64_t ldo, int32_t heads, floa
 
 }  // namespace
 
-extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
-                                              const float* a_t2s, const float* a_s2t,
-                                              const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
-                                              int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
-                                              float* out, int64_t ldo, float* alpha_opt,
-                                              const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
-                                              float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
-                                              double* colsum_opt, uint32_t* tile_queue_opt, void* stream) {
+static int aggregate_impl(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                          const float* a_t2s, const float* a_s2t,
+                          const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                          int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
+                          float* out, int64_t ldo, float* alpha_opt,
+                          const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                          float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
+                          double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, void* stream) {
   if (colsum_opt && heads != 1) return BGNN_E_SHAPE;
   if (part == 1 && (park_begin < row_begin || park_begin > row_end)) return BGNN_E_SHAPE;
   if (part < 0 || part > 3 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
@@ -995,7 +1269,32 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
     hipError_t e = bgnn_zero_async(tile_queue_opt, 8 * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
   }
-  return dispatch_aggregate(p, st);
+  return dispatch_aggregate(p, st, table_rows);
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                              const float* a_t2s, const float* a_s2t,
+                                              const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                              int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
+                                              float* out, int64_t ldo, float* alpha_opt,
+                                              const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                              float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
+                                              double* colsum_opt, uint32_t* tile_queue_opt, void* stream) {
+  return aggregate_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope, out, ldo, alpha_opt,
+                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, 0, stream);
+}
+
+extern "C" int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                                      const float* a_t2s, const float* a_s2t,
+                                                      const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                                      int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
+                                                      float* out, int64_t ldo, float* alpha_opt,
+                                                      const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                                      float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
+                                                      double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, void* stream) {
+  if (table_rows < row_end) return BGNN_E_SHAPE;
+  return aggregate_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope, out, ldo, alpha_opt,
+                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, table_rows, stream);
 }
 
 extern "C" size_t bgnn_aggregate_hub_workspace_bytes(int64_t n_segments, int32_t heads, int64_t ldo) {
@@ -1041,7 +1340,7 @@ extern "C" int bgnn_adaptedconv_aggregate_hub_f32(const float* h_t2s, const floa
   if (n_hubs > 0) {                                    // the hub rows' segments ride in the same launch as virtual rows
     p.vrow_node = seg_node; p.vrow_bounds = seg_bounds; p.n_vrows = n_segments; p.vout = part_acc; p.vms = part_ms;
   }
-  int rc = dispatch_aggregate(p, st);
+  int rc = dispatch_aggregate(p, st, N);              // (all N rows, square: every id in `col` is a row)
   if (rc || n_hubs == 0) return rc;
   HubMergeParams mp{hub_rows, hub_seg_ptr, n_hubs, part_acc, part_ms, mask, D, ldo, heads, out, ep_scale_opt, ep_shift_opt,
                     ep_relu, colsum_opt, part == 3 ? state_ms_opt : nullptr, alpha_opt, rowptr};

@@ -561,13 +561,14 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
                 L.ptr(seg_ptr), L.ptr(seg_bounds), L.ptr(seg_node), nseg, L.ptr(alpha), L.ptr(ws), wsb, L.stream())
             L.check(rc, "bgnn_adaptedconv_aggregate_hub_f32")
             return (out, alpha) if want_alpha else out
-    rc = lib.bgnn_adaptedconv_aggregate_f32(
+    # the tables' row count bounds every id in csr.col (a CSR over these tables): lets the plain wide launch use 32-bit addressing
+    rc = lib.bgnn_adaptedconv_aggregate_bounded_f32(
         L.ptr_rows(h_t2s), L.ptr_rows(h_s2t), ldh, L.ptr(a_t2s), L.ptr(a_s2t), L.ptr(csr.rowptr), L.ptr(csr.col),
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
         L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part),
         int(row_begin) if park_begin is None else int(park_begin), int(heads), L.ptr(colsum),
-        L.ptr(tq) if not (part == 2 and _P2_STATIC) else None, L.stream())
-    L.check(rc, "bgnn_adaptedconv_aggregate_f32")
+        L.ptr(tq) if not (part == 2 and _P2_STATIC) else None, min(int(h_t2s.shape[0]), int(h_s2t.shape[0])), L.stream())
+    L.check(rc, "bgnn_adaptedconv_aggregate_bounded_f32")
     return (out, alpha) if want_alpha else out
 
 

@@ -26,8 +26,9 @@ extern "C" {
 /* ABI revision.  110 (round 3) is NOT call-compatible with 100: `bgnn_transform_bwd_prep_f32` takes 22 arguments (was 17)
  * and the `n_fallback_opt` of `bgnn_cosine_topk_f32` / `bgnn_mlp_pair_topk_f32` is int32[2] (was int32[1]) -- a caller built
  * against the old header must be recompiled; compare bgnn_version() with the BGNN_VERSION it was built with at load time.
- * 111 adds bgnn_adaptedconv_transform_need_f32, 112 bgnn_classifier_stage_f32 (both call-compatible with 110). */
-#define BGNN_VERSION 112
+ * 111 adds bgnn_adaptedconv_transform_need_f32, 112 bgnn_classifier_stage_f32, 113 bgnn_adaptedconv_aggregate_bounded_f32 (all
+ * call-compatible with 110). */
+#define BGNN_VERSION 113
 #define BGNN_E_NULL (-1)        /* required pointer is NULL                     */
 #define BGNN_E_SHAPE (-2)       /* unsupported / inconsistent shape             */
 #define BGNN_E_WORKSPACE (-3)   /* ws_bytes smaller than *_workspace_bytes()    */
@@ -257,6 +258,21 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
                                    const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                    float* state_ms_opt, int part, int64_t park_begin, int32_t heads, double* colsum_opt,
                                    uint32_t* tile_queue_opt, void* stream);
+
+/* bgnn_adaptedconv_aggregate_f32 with one more promise from the caller (ABI 113): both tables have `table_rows` rows and every id in
+ * `col` is below it (table_rows >= row_end, else BGNN_E_SHAPE).  Results are bit-identical; the promise lets the plain wide launch
+ * (heads = 1, part = 0, no alpha, D > 32) address neighbour rows by 32-bit offsets inside one window that holds both tables, when
+ * that window is below 4 GB and table_rows <= 2^24 (agg_wide_fast_kernel: C4 hidden conv 1.06 -> see DESIGN 4.1); every other
+ * shape runs exactly what bgnn_adaptedconv_aggregate_f32 runs.  Ids >= table_rows read outside the tables (undefined), as they
+ * do there.  BGNN_AGG_FAST=0 in the environment keeps the general kernel. */
+int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
+                                           const float* a_t2s, const float* a_s2t,
+                                           const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
+                                           int64_t row_begin, int64_t row_end, int32_t D, float negative_slope,
+                                           float* out, int64_t ldo, float* alpha_opt,
+                                           const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
+                                           float* state_ms_opt, int part, int64_t park_begin, int32_t heads, double* colsum_opt,
+                                           uint32_t* tile_queue_opt, int64_t table_rows, void* stream);
 
 /* The same aggregation for graphs with HUB rows.  A destination row is walked by one lane group, so a row with hundreds of
  * in-edges (the 581 source nodes of the Twitter_Graph stand-in have ~750) is a chain of dependent gather steps that outlives

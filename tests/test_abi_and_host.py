@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in bgnn.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES out of sync with include/bgnn.h"
     l = _lib.lib()
-    assert l.bgnn_version() == _lib.ABI_VERSION == 112
+    assert l.bgnn_version() == _lib.ABI_VERSION == 113
     assert b"NULL" in l.bgnn_error_string(-1) and l.bgnn_error_string(0) == b"success"
 
 

@@ -1,0 +1,88 @@
+"""GPU: round-3 kernels -- the 32-bit-addressed plain wide aggregation (agg_wide_fast_kernel, ABI 113) against the general
+kernel bit for bit and against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _general(tS, tT, a1, a2, csr, m8, D, slope, sc, sh, relu, sums, row_begin, row_end, out):
+    """bgnn_adaptedconv_aggregate_f32: no table_rows promise -> always the general kernel (agg_wide_kernel for D > 32)"""
+    from bridged_gnn_amd import _lib as L, ops
+    tq = ops._tile_queue(tS.device)
+    rc = L.lib().bgnn_adaptedconv_aggregate_f32(
+        L.ptr_rows(tS), L.ptr_rows(tT), tS.stride(0), L.ptr(a1), L.ptr(a2), L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(m8),
+        row_begin, row_end, D, slope, L.ptr_rows(out), out.stride(0), None, L.ptr(sc), L.ptr(sh), 1 if relu else 0, None, 0, row_begin, 1,
+        L.ptr(sums), L.ptr(tq), L.stream())
+    L.check(rc, "bgnn_adaptedconv_aggregate_f32")
+    return out
+
+
+@pytest.mark.parametrize("D,n,deg,seed", [(128, 5000, 9, 0), (100, 3001, 5, 1), (36, 777, 3, 2), (64, 4096, 12, 3), (200, 1500, 7, 4),
+                                          (256, 900, 4, 5), (128, 9, 2, 6), (128, 20000, 21, 7)])
+def test_fast_wide_aggregation_is_bit_identical_to_the_general_kernel(D, n, deg, seed):
+    """Same arithmetic, different addressing: the two kernels must agree in every bit of the rows (the column sums are order-dependent
+    fp32 partials in both); both meet the 1e-5 bar against the fp64 evaluation of KTGNN.py:292-305."""
+    from bridged_gnn_amd import ops, synth
+    rng = np.random.default_rng(3000 + seed)
+    ei, mask = synth.random_multigraph(n, deg * n, frac_src=float(rng.uniform(0.2, 0.8)), n_isolated=min(3, n // 4), seed=seed)
+    slope = float(rng.choice([0.0, 0.1, 0.2, 1.0]))
+    hS, hT = rng.standard_normal((n, D)).astype(np.float32), rng.standard_normal((n, D)).astype(np.float32)
+    a1, a2 = (rng.standard_normal(D) * 0.3).astype(np.float32), (rng.standard_normal(D) * 0.3).astype(np.float32)
+    csr = ops.build_dst_csr(_t(ei), n)
+    assert csr.hub_tables() is None                      # (hub rows take the general kernel: test_degree_skew_hub_rows)
+    ld = ops.pad4(D)
+    both = torch.zeros(2, n, ld, device=DEV)             # one allocation: the two tables share a window
+    tS, tT = both[0], both[1]
+    tS[:, :D], tT[:, :D] = _t(hS), _t(hT)
+    m8 = _t(mask).to(torch.uint8)
+    sc = _t(rng.uniform(0.5, 1.5, D).astype(np.float32)); sh = _t(rng.standard_normal(D).astype(np.float32))
+    a1t, a2t = _t(a1), _t(a2)
+    for relu, with_ep, (rb, re) in ((True, True, (0, n)), (False, False, (0, n)), (True, True, (n // 3, n - n // 5))):
+        s_fast = torch.zeros(2 * ld + 2, dtype=torch.float64, device=DEV)
+        s_gen = torch.zeros_like(s_fast)
+        o_fast = torch.full((n, ld), 7.0, device=DEV)
+        o_gen = torch.full((n, ld), 7.0, device=DEV)
+        ep = dict(ep_scale=sc, ep_shift=sh) if with_ep else {}
+        ops.adaptedconv_aggregate(tS, tT, a1t, a2t, csr, m8, D, slope, ep_relu=relu, colsum=s_fast, out=o_fast, row_begin=rb, row_end=re, **ep)
+        _general(tS, tT, a1t, a2t, csr, m8, D, slope, sc if with_ep else None, sh if with_ep else None, relu, s_gen, rb, re, o_gen)
+        torch.cuda.synchronize()
+        assert torch.equal(o_fast, o_gen), f"D={D} n={n} rows [{rb},{re}) relu={relu}: {(o_fast != o_gen).sum().item()} elements differ"
+        assert (o_fast[:rb] == 7.0).all() and (o_fast[re:] == 7.0).all()             # rows outside the range untouched
+        # (column sums: fp32 partials per lane over the rows the dynamic tile queue handed it -- order-dependent in both kernels)
+        torch.testing.assert_close(s_fast, s_gen, rtol=2e-6, atol=1e-3)
+        assert s_fast[2 * ld].item() == mask[rb:re].sum() and s_fast[2 * ld + 1].item() == (~mask[rb:re]).sum()
+    rowptr, col, _ = O.dst_csr(ei, mask)
+    truth = OC.adaptedconv_aggregate_f64(hS, hT, a1, a2, rowptr, col, mask, slope=slope)
+    out = ops.adaptedconv_aggregate(tS, tT, a1t, a2t, csr, m8, D, slope)
+    assert_close(out[:, :D].cpu().numpy(), truth, what=f"fast wide aggregation vs fp64 truth D={D} n={n}")
+    assert (out[:, D:] == 0).all()
+
+
+def test_fast_wide_aggregation_falls_back_when_the_tables_are_4gb_apart():
+    """Two tables whose window exceeds 32 bits of byte offsets take the general kernel: same result, no fault."""
+    from bridged_gnn_amd import ops, synth
+    n, D = 2000, 128
+    rng = np.random.default_rng(5)
+    ei, mask = synth.random_multigraph(n, 6 * n, frac_src=0.5, n_isolated=2, seed=11)
+    csr = ops.build_dst_csr(_t(ei), n)
+    big = torch.empty((1 << 30) + (1 << 18) + n * D, dtype=torch.float32, device=DEV)   # the tables 4 GB + 1 MB apart, one allocation
+    tS, tT = big[:n * D].view(n, D), big[(1 << 30) + (1 << 18):].view(n, D)
+    tS.copy_(_t(rng.standard_normal((n, D)).astype(np.float32))); tT.copy_(_t(rng.standard_normal((n, D)).astype(np.float32)))
+    a1, a2 = _t((rng.standard_normal(D) * 0.3).astype(np.float32)), _t((rng.standard_normal(D) * 0.3).astype(np.float32))
+    m8 = _t(mask).to(torch.uint8)
+    assert tT.data_ptr() - tS.data_ptr() > (1 << 32)
+    far = ops.adaptedconv_aggregate(tS, tT, a1, a2, csr, m8, D, 0.1)
+    both = torch.stack([tS, tT])
+    near = ops.adaptedconv_aggregate(both[0], both[1], a1, a2, csr, m8, D, 0.1)
+    assert torch.equal(far, near)
