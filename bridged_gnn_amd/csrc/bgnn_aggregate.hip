@@ -69,6 +69,7 @@ struct AggParams {
   // agg_wide_fast_kernel only (filled by fast_plan): both tables inside ONE window of < 4 GB, addressed by 32-bit byte offsets
   const char* tbl_base;
   uint32_t tbl_bytes, off_t2s, off_s2t;
+  uint32_t dead_off;   // row offset of a dead slot: lane base + dead_off is past the window and below 2^32, or 0 (row 0) when that does not fit
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -691,35 +692,46 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
     const uint32_t lbase = (dom_s ? p.off_t2s : p.off_s2t) + (uint32_t)f0c * 4u;     // this lane's columns of row 0 of its table
     const f2 a01 = dom_s ? aS01 : aT01, a23 = dom_s ? aS23 : aT23;
     const float4 hi4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + __umul24((uint32_t)ic, nstride), 0, 0));
-    const f2 h01 = {hi4.x, hi4.y}, h23 = {hi4.z, hi4.w};
+    f2 h01 = {hi4.x, hi4.y}, h23 = {hi4.z, hi4.w};
 
     float m = -INFINITY, s = 0.f;          // s: per-lane partial (sum over the steps of "my" edge slot)
     f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     const int32_t niter = (end - beg + U - 1) / U;
-    int32_t e = beg + k;
-    bool ok = e < end;
-    uint32_t myoff = 0;                    // byte offset of my slot's neighbour row inside its table
-    if (niter > 0) myoff = __umul24((uint32_t)p.col[min(e, end - 1)], nstride);
-    for (int32_t it = 0; it < niter; ++it) {
-      float4 v[U];
-      v[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x00>(myoff), 0, 0));
-      v[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x55>(myoff), 0, 0));
-      v[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xAA>(myoff), 0, 0));
-      v[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xFF>(myoff), 0, 0));
-      // next step's id: an UNCONDITIONAL load (a slot past the end re-reads the row's last id and is dead by `ok`): behind a
-      // branch the compiler waits for it -- and for the four gathers issued before it -- inside the branch
-      const int32_t e2 = e + U;
-      const bool ok2 = e2 < end;
-      // Issued HERE, behind the gathers, as inline assembly: written as `p.col[..]` the compiler sinks the load (its only use is the
-      // next iteration's offset) to the loop top, where the gathers then wait for it -- two dependent round trips per step.  The
-      // compiler does not count this load in its s_waitcnt vmcnt(n): it then waits for one load more than it needs, never less
-      // (loads return in order); the value itself is taken behind the explicit wait at the end of the step.
-      uint32_t nextid;
-      const uint32_t e2off = (uint32_t)min(e2, end - 1) * 4u;
-      __builtin_amdgcn_sched_barrier(0);           // the four gathers and this load go out back to back, nothing scheduled between them
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(nextid) : "v"(e2off), "s"(p.col) : "memory");
+    // the four gathers of a step: offset = this lane's column base + the quad-broadcast row offset of slot u
+    auto issue = [&](float4 (&v)[U], uint32_t off) {
+      v[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x00>(off), 0, 0));
+      v[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0x55>(off), 0, 0));
+      v[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xAA>(off), 0, 0));
+      v[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, lbase + dpp_movu<0xFF>(off), 0, 0));
+      // Issued HERE.  Instruction selection orders pure arithmetic freely against loads and barriers (and likes to push four
+      // 16-byte loads behind the other buffer's arithmetic to save registers): the empty statement below clobbers memory, so the
+      // loads above stay in front of it, and redefines the row's own h, which every score of update() reads, so that arithmetic
+      // stays behind it.  No instruction, no wait (it names no register a load is writing).
+      asm volatile("" : "+v"(h01), "+v"(h23) : : "memory");
       __builtin_amdgcn_sched_barrier(0);
-
+    };
+    // take the id requested by load_id.  The step's state rides through the statement so that all of update() is in front of the wait.
+    auto take_id = [&](uint32_t& id) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(id), "+v"(m), "+v"(s), "+v"(acc01), "+v"(acc23) : : "memory");
+    };
+    // The id of a later step's slot, as INLINE ASSEMBLY: written as `p.col[..]` the compiler sinks the load (its only use is a later
+    // iteration's offset) to the loop top, in front of the gathers that need it -- two dependent round trips per step.  The
+    // compiler does not count this load in its s_waitcnt vmcnt(n): it then waits for one load more than it needs, never less
+    // (loads return in order); the value is taken behind an explicit wait (take_id).  A slot past the end re-reads the row's
+    // last id (valid memory) and is dead by its `ok` bit.
+    auto load_id = [&](int32_t ee) {
+      uint32_t id;
+      const uint32_t eoff = (uint32_t)max(min(ee, end - 1), 0) * 4u;     // (an empty row rides along with its wave: col[0])
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(id) : "v"(eoff), "s"(p.col) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return id;
+    };
+    // dead slots gather nothing: their offset lies past the window (the buffer's range check returns zeros), see fast_plan
+    auto row_off = [&](uint32_t id, bool alive) { return alive ? __umul24(id, nstride) : p.dead_off; };
+    // score + online-softmax update of one step whose rows are in v
+    auto update = [&](const float4 (&v)[U], bool ok) {
       float t[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -750,16 +762,40 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
         acc01.x = fmaf(w, v[u].x, acc01.x); acc01.y = fmaf(w, v[u].y, acc01.y); \
         acc23.x = fmaf(w, v[u].z, acc23.x); acc23.y = fmaf(w, v[u].w, acc23.y); \
       }
+#ifdef AGGF_X_NOACC      /* ablation (tools/exp_libs): a step without its 12 accumulate instructions -- is the launch VALU-bound? */
+      acc01.x += pe * v[0].x + v[1].y + v[2].z + v[3].w;
+#else
       { const float w = quad_bcast<0>(pe); BGNN_ACC(0, w) }
       { const float w = quad_bcast<1>(pe); BGNN_ACC(1, w) }
       { const float w = quad_bcast<2>(pe); BGNN_ACC(2, w) }
       { const float w = quad_bcast<3>(pe); BGNN_ACC(3, w) }
+#endif
 #undef BGNN_ACC
       m = mn;
-      e = e2; ok = ok2;
-      __builtin_amdgcn_sched_barrier(0);           // (the wait stays behind the step's arithmetic)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nextid) : : "memory");
-      myoff = __umul24(nextid, nstride);
+    };
+    // The step loop is WAVE-UNIFORM: every row of the wave runs the longest row's step count.  A step past a row's end is dead
+    // in all four slots -- no traffic (dead_off), l = -inf, weight 0: m, s and the accumulator pass through unchanged -- and its
+    // lanes would idle in lockstep anyway.  A scalar trip count keeps exec-mask bookkeeping out of the loop.
+    // (Two steps in flight -- buffers A / B, the next step's gathers issued before this step is scored -- measured 0.953 vs
+    //  0.933 ms at 111 VGPRs / 4 waves per SIMD; a step without its 12 accumulate instructions 0.918 vs 0.942 ms: neither the
+    //  latency of a wave nor the VALU is the bound, the gather rate is.  profiles/r03/README.md)
+    int32_t nw = __builtin_amdgcn_readlane(niter, 0);
+    if constexpr (LF <= 32) nw = max(nw, __builtin_amdgcn_readlane(niter, 32));
+    if constexpr (LF <= 16) nw = max(nw, max(__builtin_amdgcn_readlane(niter, 16), __builtin_amdgcn_readlane(niter, 48)));
+    int32_t e = beg + k;
+    bool ok = e < end;
+    uint32_t myoff = p.dead_off;           // byte offset of my slot's neighbour row inside its table
+    if (nw > 0) myoff = row_off((uint32_t)p.col[max(min(e, end - 1), 0)], ok);
+    for (int32_t it = 0; it < nw; ++it) {
+      float4 v[U];
+      issue(v, myoff);
+      e += U;
+      const bool ok2 = e < end;
+      uint32_t nextid = load_id(e);        // behind the gathers
+      update(v, ok);
+      ok = ok2;
+      take_id(nextid);
+      myoff = row_off(nextid, ok);
     }
     s += bgnn::dpp_mov<0xB1>(s);
     s += bgnn::dpp_mov<0x4E>(s);
@@ -1036,6 +1072,9 @@ static bool fast_plan(AggParams& p, int64_t table_rows) {
   p.tbl_bytes = (uint32_t)span;
   p.off_t2s = (uint32_t)(a - lo);
   p.off_s2t = (uint32_t)(b - lo);
+  // lane base < (offset of the upper table) + (row stride); a dead slot's address must stay in [window, 2^32)
+  const int64_t lane_max = (span - table_rows * p.ldh * 4) + p.ldh * 4, dead = (((int64_t)1 << 32) - 16) - lane_max;
+  p.dead_off = dead >= span ? (uint32_t)dead : 0u;
   return true;
 }
 
