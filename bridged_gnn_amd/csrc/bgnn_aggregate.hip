@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
   }
 }
 
-// ---- wide rows, the plain launch (heads == 1, mode 0, no hub segments, no alpha) with 32-bit addressing ------------------------
+// ---- wide rows, the plain launch (heads == 1, mode 0, no hub segments) with 32-bit addressing -----------------------------------
 // agg_wide_kernel is VALU-bound on gfx950 (PMC, C4: VALU busy 78 % of the launch, 440 M wave instructions: ~105 per step of
 // U = 4 edges x 2 rows plus ~230 per row pair of set-up / epilogue), not gather-bound.  This variant drops what the plain
 // launch does not need, in the SAME arithmetic order (results are bit-identical to agg_wide_kernel, tests pin that):
@@ -591,14 +591,15 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggParams p) {
 //    four gathers of a step take their offset as `lane base + quad-broadcast(offset)`, one v_add_u32 with a DPP operand
 //    each -- instead of per edge: a DPP move, a clamp and a quarter-rate v_mad_u64_u32 (4 issue slots);
 //  * a slot past the row's end carries offset 0 and a `valid` bit instead of id -1 + clamp;
-//  * row set-up in 32-bit integers, no (row, head) division, no virtual-row / two-part / alpha branches;
+//  * row set-up in 32-bit integers, no (row, head) division, no virtual-row / two-part branches (ALPHA: the training forward's
+//    attention coefficients, written exactly as agg_wide_kernel writes them);
 //  * the per-domain column sums take the row with weight 1 / 0 (packed FMAs) instead of two divergent branches.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_movu(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true); }
 
-template <int LF>
+template <int LF, bool ALPHA>
 __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
   static_assert(LF == 16 || LF == 32 || LF == 64, "wide rows only");
   constexpr int U = 4;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
     // dead slots gather nothing: their offset lies past the window (the buffer's range check returns zeros), see fast_plan
     auto row_off = [&](uint32_t id, bool alive) { return alive ? __umul24(id, nstride) : p.dead_off; };
     // score + online-softmax update of one step whose rows are in v
-    auto update = [&](const float4 (&v)[U], bool ok) {
+    auto update = [&](const float4 (&v)[U], bool ok, int32_t e_cur) {
       float t[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -749,6 +750,9 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
       if constexpr (LF >= 32) r += bgnn::swz_xor16(r);
       if constexpr (LF >= 64) r += __shfl_xor(r, 32);
       const float l = ok ? r : -INFINITY;
+      if constexpr (ALPHA) {
+        if (lg < U && ok) p.alpha[e_cur] = l;                // raw logit of my slot, normalised below by the same lane
+      }
       float cm = fmaxf(l, bgnn::dpp_mov<0xB1>(l));
       cm = fmaxf(cm, bgnn::dpp_mov<0x4E>(cm));
       const float mn = fmaxf(m, cm);
@@ -789,10 +793,11 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
     for (int32_t it = 0; it < nw; ++it) {
       float4 v[U];
       issue(v, myoff);
+      const int32_t e_cur = e;
       e += U;
       const bool ok2 = e < end;
       uint32_t nextid = load_id(e);        // behind the gathers
-      update(v, ok);
+      update(v, ok, e_cur);
       ok = ok2;
       take_id(nextid);
       myoff = row_off(nextid, ok);
@@ -801,6 +806,11 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
     s += bgnn::dpp_mov<0x4E>(s);
 
     const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
+    if constexpr (ALPHA) {
+      if (lg < U) {                          // the lane that wrote a raw logit normalises it (program order, no fence)
+        for (int32_t e2 = beg + lg; e2 < end; e2 += U) p.alpha[e2] = __expf(p.alpha[e2] - m) * inv;
+      }
+    }
     if (rvalid && f0 < p.ldo) {
       float4 o = make_float4(acc01.x * inv, acc01.y * inv, acc23.x * inv, acc23.y * inv);
       if (p.ep_scale != nullptr) {
@@ -1060,7 +1070,7 @@ int launch_wide(const AggParams& p, hipStream_t st) {
 static bool fast_plan(AggParams& p, int64_t table_rows) {
   static const bool on = [] { const char* e = getenv("BGNN_AGG_FAST"); return !(e && atoi(e) == 0); }();
   if (!on || table_rows <= 0) return false;
-  if (p.heads != 1 || p.mode != 0 || p.alpha != nullptr || p.n_vrows != 0 || p.hub_threshold != 0) return false;
+  if (p.heads != 1 || p.mode != 0 || p.n_vrows != 0 || p.hub_threshold != 0) return false;
   const int64_t lim24 = (int64_t)1 << 24, lim32 = ((int64_t)1 << 32) - 1;       // v_mul_u32_u24 operands / 32-bit byte offsets
   if (table_rows > lim24 || p.row_end > table_rows || p.ldh * 4 >= lim24 || p.ldo * 4 >= lim24) return false;
   const char* a = reinterpret_cast<const char*>(p.h_t2s);
@@ -1078,14 +1088,14 @@ static bool fast_plan(AggParams& p, int64_t table_rows) {
   return true;
 }
 
-template <int LF>
+template <int LF, bool ALPHA>
 int launch_wide_fast(const AggParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / LF);
   static const int cap = [] {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_fast_kernel<LF>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_fast_kernel<LF, ALPHA>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
     if (per_cu > 8) per_cu = 8;
     const char* e = getenv("BGNN_AGG_BLOCKS_PER_CU");
     if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
@@ -1100,7 +1110,7 @@ int launch_wide_fast(const AggParams& p, hipStream_t st) {
   q.tq_interleave = il;
   static const int nseg = [] { const char* e = getenv("BGNN_XCD_SEGMENTS"); return e ? atoi(e) : 8; }();
   q.xcd_segments = nseg;
-  hipLaunchKernelGGL((agg_wide_fast_kernel<LF>), dim3((unsigned)grid), dim3(256), 0, st, q);
+  hipLaunchKernelGGL((agg_wide_fast_kernel<LF, ALPHA>), dim3((unsigned)grid), dim3(256), 0, st, q);
   BGNN_LAUNCH_CHECK();
   return 0;
 }
@@ -1256,9 +1266,14 @@ static int dispatch_aggregate(const AggParams& p, hipStream_t st, int64_t table_
   if (wide_ok) {
     AggParams q = p;
     if (fast_plan(q, table_rows)) {
-      if (nv <= 16) return launch_wide_fast<16>(q, st);
-      if (nv <= 32) return launch_wide_fast<32>(q, st);
-      return launch_wide_fast<64>(q, st);
+      if (q.alpha != nullptr) {
+        if (nv <= 16) return launch_wide_fast<16, true>(q, st);
+        if (nv <= 32) return launch_wide_fast<32, true>(q, st);
+        return launch_wide_fast<64, true>(q, st);
+      }
+      if (nv <= 16) return launch_wide_fast<16, false>(q, st);
+      if (nv <= 32) return launch_wide_fast<32, false>(q, st);
+      return launch_wide_fast<64, false>(q, st);
     }
     if (nv <= 16) return launch_wide<16, 4>(p, st);
     if (nv <= 32) return launch_wide<32, 4>(p, st);

@@ -16,13 +16,13 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def _general(tS, tT, a1, a2, csr, m8, D, slope, sc, sh, relu, sums, row_begin, row_end, out):
+def _general(tS, tT, a1, a2, csr, m8, D, slope, sc, sh, relu, sums, row_begin, row_end, out, alpha=None):
     """bgnn_adaptedconv_aggregate_f32: no table_rows promise -> always the general kernel (agg_wide_kernel for D > 32)"""
     from bridged_gnn_amd import _lib as L, ops
     tq = ops._tile_queue(tS.device)
     rc = L.lib().bgnn_adaptedconv_aggregate_f32(
         L.ptr_rows(tS), L.ptr_rows(tT), tS.stride(0), L.ptr(a1), L.ptr(a2), L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(m8),
-        row_begin, row_end, D, slope, L.ptr_rows(out), out.stride(0), None, L.ptr(sc), L.ptr(sh), 1 if relu else 0, None, 0, row_begin, 1,
+        row_begin, row_end, D, slope, L.ptr_rows(out), out.stride(0), L.ptr(alpha), L.ptr(sc), L.ptr(sh), 1 if relu else 0, None, 0, row_begin, 1,
         L.ptr(sums), L.ptr(tq), L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_f32")
     return out
@@ -62,6 +62,14 @@ def test_fast_wide_aggregation_is_bit_identical_to_the_general_kernel(D, n, deg,
         # (column sums: fp32 partials per lane over the rows the dynamic tile queue handed it -- order-dependent in both kernels)
         torch.testing.assert_close(s_fast, s_gen, rtol=2e-6, atol=1e-3)
         assert s_fast[2 * ld].item() == mask[rb:re].sum() and s_fast[2 * ld + 1].item() == (~mask[rb:re]).sum()
+    # the training forward's launch: attention coefficients in CSR order, written by the same lanes in the same order
+    o_fast, al_fast = ops.adaptedconv_aggregate(tS, tT, a1t, a2t, csr, m8, D, slope, want_alpha=True)
+    al_gen = torch.full_like(al_fast, -1.0)
+    o_gen = _general(tS, tT, a1t, a2t, csr, m8, D, slope, None, None, False, None, 0, n, torch.empty_like(o_fast), alpha=al_gen)
+    assert torch.equal(o_fast, o_gen) and torch.equal(al_fast, al_gen)
+    rp = csr.rowptr.long()
+    seg = torch.repeat_interleave(torch.arange(n, device=DEV), rp[1:] - rp[:-1])
+    torch.testing.assert_close(torch.zeros(n, device=DEV).index_add_(0, seg, al_fast), torch.ones(n, device=DEV), rtol=0, atol=2e-6)
     rowptr, col, _ = O.dst_csr(ei, mask)
     truth = OC.adaptedconv_aggregate_f64(hS, hT, a1, a2, rowptr, col, mask, slope=slope)
     out = ops.adaptedconv_aggregate(tS, tT, a1t, a2t, csr, m8, D, slope)
