@@ -96,7 +96,7 @@ def source_hash():
 
 # keep in step with HASHED in csrc/Makefile
 _HASHED_SOURCES = ("bgnn_api.hip", "bgnn_csr.hip", "bgnn_transform.hip", "bgnn_transform_stream.hip", "bgnn_transform_cls.hip", "bgnn_aggregate.hip", "bgnn_aggregate_bwd.hip",
-                   "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", "bgnn_transform_params.h", os.path.join("..", "..", "include", "bgnn.h"))
+                   "bgnn_aggregate_bwd_fast.hip", "bgnn_knn.hip", "bgnn_gram.hip", "bgnn_norm.hip", "bgnn_common.h", "bgnn_transform_params.h", "bgnn_aggregate_bwd_params.h", os.path.join("..", "..", "include", "bgnn.h"))
 
 
 def _sidecar_hash():

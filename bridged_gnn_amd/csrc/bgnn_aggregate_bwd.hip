@@ -14,6 +14,7 @@
 // row group owns the feature columns {l, l+LF, l+2LF, l+3LF} instead of a float4.
 // Atomic sums are order-dependent in the last bits (like torch's scatter_add backward on GPUs).
 #include "bgnn_common.h"
+#include "bgnn_aggregate_bwd_params.h"
 
 namespace {
 
@@ -141,26 +142,7 @@ int launch_bwd(const BwdParams& p, hipStream_t st) {
 //   pass B (by source): for every out-edge j -> i gather dL/dout_i (4 lines) and the record (1 line), rebuild
 //          alpha g_i + de (a * leaky') in registers and write each dH row exactly once (no zero-fill, no atomics,
 //          deterministic).
-struct PullParams {
-  const float* h_t2s; const float* h_s2t; int64_t ldh;
-  const float* a_t2s; const float* a_s2t;
-  const int32_t* rowptr; const int32_t* col; const uint8_t* mask;
-  int64_t N; int32_t D; float slope;
-  const float* out; int64_t ldo; const float* alpha; const float* gout; int64_t ldg;
-  const int32_t* t_rowptr; const int32_t* t_eid; const int32_t* t_dst;
-  uint4* rec;            // [E'][2]
-  unsigned int* queue;   // [16] per-XCD dynamic tile counters (pass A: 0..7, pass B: 8..15), zeroed per call
-  float* dstside;        // [N][ldh]
-  float* dh_t2s; float* dh_s2t; float* da_t2s; float* da_s2t;
-  // Hub rows (wide kernels; the forward's scheme, bgnn_aggregate.hip AggParams): a row is walked by one lane group, so a row of
-  // ~750 edges (the Twitter_Graph stand-in's source nodes) is a chain of ~190 dependent steps.  Rows with >= hub_threshold edges
-  // are skipped as rows and walked as <= 64-edge segments that ride behind the real rows of the same launch; a segment leaves
-  // its partial row sums in scratch and a merge launch adds them in a fixed order (deterministic like the rest).  Pass A
-  // segments destinations by in-degree (d_*), pass B sources by out-degree (s_*, offsets into the by-source arrays).
-  int32_t hub_threshold;
-  const int32_t* d_vnode; const int32_t* d_vbounds; int64_t d_nv; float* d_vpart;                 // [d_nv][ldh]
-  const int32_t* s_vnode; const int32_t* s_vbounds; int64_t s_nv; float* s_vpartS; float* s_vpartT;   // [s_nv][ldh] each
-};
+using bgnn_bwd::PullParams;
 
 template <int LF>
 __global__ __launch_bounds__(256) void agg_bwd_dst_kernel(PullParams p) {
@@ -907,6 +889,8 @@ static int pull_impl(const float* h_t2s, const float* h_s2t, int64_t ldh, const 
   if (bgnn_zero_async(queue, 16 * sizeof(unsigned int), st) != hipSuccess) return (int)hipErrorInvalidValue;
   if (narrow) return launch_pull_narrow(p, st);
   const int nv = (D + 3) / 4;
+  p.E = E;
+  if (!hubs && nv > 16 && bgnn_bwd::pull_fast_plan(p)) return bgnn_bwd::pull_fast_launch(p, st);
   if (nv <= 2) return launch_pull<2>(p, st, hubs);
   if (nv <= 4) return launch_pull<4>(p, st, hubs);
   if (nv <= 8) return launch_pull<8>(p, st, hubs);

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../bridged_gnn_amd/csrc"
 make -s -j4
 mkdir -p ../../tools/exp_libs
 objs=""
-for f in bgnn_api bgnn_csr bgnn_transform bgnn_transform_stream bgnn_transform_cls bgnn_aggregate bgnn_aggregate_bwd bgnn_knn bgnn_gram bgnn_norm; do
+for f in bgnn_api bgnn_csr bgnn_transform bgnn_transform_stream bgnn_transform_cls bgnn_aggregate bgnn_aggregate_bwd bgnn_aggregate_bwd_fast bgnn_knn bgnn_gram bgnn_norm; do
   if [ "$f.hip" == "$2" ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-fast-math -Wno-unused-function $3 -c $f.hip -o ../../tools/exp_libs/$1.o
     objs="$objs ../../tools/exp_libs/$1.o"
