@@ -698,7 +698,7 @@ def main():
         achieved = bytes_launch / (agg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args, world, args.graph if args.config == "c4" else "fixed")
         gather_bytes = e_local * 4 * args.hidden                       # the row gathers alone (what the L2s serve)
-        kern = f"agg_wide_kernel<D={args.hidden}> (hidden AdaptedConv aggregation)"
+        kern = f"agg_wide_fast_kernel<LF={max(16, 1 << (max(args.hidden - 1, 1) // 4).bit_length())}> (hidden AdaptedConv aggregation, D={args.hidden}; agg_wide_kernel when the launch is outside the 32-bit-addressing envelope)"
         tnote = ("PMC FETCH_SIZE x2 + WRITE_SIZE per launch from the committed rocprofv3 passes named in `traffic_source` (separate "
                  "--pmc runs of this command, NOT collected by this run); the counters sit on the fabric side of the L2s, so "
                  "Infinity-Cache hits are included (MI355X_MICROARCH: HBM)")

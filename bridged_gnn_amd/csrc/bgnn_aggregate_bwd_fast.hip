@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_fast_kernel(PullParams p) {
         u32x2_t hd = {__builtin_bit_cast(unsigned, als), __builtin_bit_cast(unsigned, de)};
         __builtin_amdgcn_raw_buffer_store_b64(hd, rrec, ok ? (uint32_t)e_cur * 32u + 16u : OOB, 0, 0);
       }
-      uint32_t mk[U][4];
+      const int32_t eb = e_cur - k;                         // slot 0 of this step
 #define BGNN_BWD_EDGE(u)                                                                                         \
       {                                                                                                          \
         const float de_u = quad_bcast<u>(de), des_u = quad_bcast<u>(des);                                        \
@@ -193,22 +193,14 @@ __global__ __launch_bounds__(256) void agg_bwd_dst_fast_kernel(PullParams p) {
         w01 += s01; w23 += s23;                                                                                  \
         z01s = __builtin_elementwise_fma(s01, z01, z01s); z23s = __builtin_elementwise_fma(s23, z23, z23s);      \
         const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);     \
-        /* group 0's lanes take the low words (their row's edge), group 1's the high words */                         \
-        mk[u][0] = g ? (unsigned)(m0 >> 32) : (unsigned)m0;                           \
-        mk[u][1] = g ? (unsigned)(m1 >> 32) : (unsigned)m1;                           \
-        mk[u][2] = g ? (unsigned)(m2 >> 32) : (unsigned)m2;                           \
-        mk[u][3] = g ? (unsigned)(m3 >> 32) : (unsigned)m3;                           \
+        if (l == 0) { /* sign words of the edge (column 4*lane + c <-> bit lane of word c): group 0 owns the low words, group 1 the high */ \
+          const u32x4_t m = {g ? (unsigned)(m0 >> 32) : (unsigned)m0, g ? (unsigned)(m1 >> 32) : (unsigned)m1,   \
+                             g ? (unsigned)(m2 >> 32) : (unsigned)m2, g ? (unsigned)(m3 >> 32) : (unsigned)m3};  \
+          __builtin_amdgcn_raw_buffer_store_b128(m, rrec, eb + u < end ? (uint32_t)(eb + u) * 32u : OOB, 0, 0);  \
+        }                                                                                                        \
       }
       BGNN_BWD_EDGE(0) BGNN_BWD_EDGE(1) BGNN_BWD_EDGE(2) BGNN_BWD_EDGE(3)
 #undef BGNN_BWD_EDGE
-      if (l == 0) {                                         // sign words of the step's four edges (column 4*lane + c <-> bit lane of word c)
-        const int32_t eb = e_cur - k;                       // slot 0 of this step
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const u32x4_t m = {mk[u][0], mk[u][1], mk[u][2], mk[u][3]};
-          __builtin_amdgcn_raw_buffer_store_b128(m, rrec, eb + u < end ? (uint32_t)(eb + u) * 32u : OOB, 0, 0);
-        }
-      }
       ok = ok2;
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(nextid), "+v"(nextal), "+v"(w01), "+v"(w23), "+v"(z01s), "+v"(z23s) : : "memory");

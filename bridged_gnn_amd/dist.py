@@ -426,8 +426,14 @@ class PartitionedKTGNN:
                 sums = self._all_reduce(sums)
             self._x_sums, self._x_sums_key = sums, (weakref.ref(x), x._version)
         sums = self._x_sums
-        h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums,
-                                      tail_single=tuple(p.n_halo_by_table) if self.single_table_halo else (0, 0))
+        # which table(s) a 32-row tile of [own rows ; halo rows] is ever read from (a halo row feeds destinations of one domain;
+        # with s -> t bridge edges a target row's h_t2s is dead as well): generalises tail_single
+        need = self.csr_ext.tile_need(self.mask_u8, table_mask_u8=self.mask_ext_u8) if (self.single_table_halo and conv.out_channels > 32) else None
+        if need is not None:
+            h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums, tile_need=need)
+        else:
+            h_t2s, h_s2t = conv.transform(self._input_ext(x), self.mask_ext_u8, sums=sums,
+                                          tail_single=tuple(p.n_halo_by_table) if self.single_table_halo else (0, 0))
         sc, sh, relu = epilogue if epilogue is not None else (None, None, False)
         out = ops.adaptedconv_aggregate(h_t2s, h_s2t, conv.a_f_t2s.weight.detach().reshape(-1).contiguous(),
                                         conv.a_f_s2t.weight.detach().reshape(-1).contiguous(), self.csr_ext, self.mask_u8,
@@ -501,6 +507,16 @@ class PartitionedKTGNN:
         dout, din = m._tf_w0.shape
         pack_t = m._composed_target_pack(ops.pad4(dout))
         raw = None
+        if not (self.world > 1 or self.always) and s_h is not None:
+            # nothing to all-reduce: the three convs' narrow tables in ONE pass over h (bgnn_classifier_stage_f32), as the single-GPU
+            # forward does.  (With ranks the fused kernel would need the all-reduced sums of h BEFORE the pass and of T's hidden
+            # activation AFTER it -- two all-reduces instead of one; a rank's second pass over its 1/N of h costs less.)
+            res = self._classifier_stage(x, None, s_h, None, arena=arena, fuse=True)
+            if res is not None:
+                logp, fused = res
+                if not fused:
+                    logp = F.log_softmax(logp, dim=2)
+                return logp[:, 0], logp[:, 1], logp[:, 2]
         if (adjacent and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] == din
                 and ops.linear_narrow_supported(din, dout, pack_t)):
             # fused pair: h1 never reaches HBM; stage A leaves 12 floats per row + the rank-local sums of h1, stage B
@@ -525,7 +541,7 @@ class PartitionedKTGNN:
             logp = F.log_softmax(logp, dim=2)                                    # one launch for the three heads
         return logp[:, 0], logp[:, 1], logp[:, 2]
 
-    def _classifier_stage(self, x, xt, s_h, s_t, raw=None, pack_t=None):
+    def _classifier_stage(self, x, xt, s_h, s_t, raw=None, pack_t=None, arena=None, fuse=False):
         """clf_base(x), clf_target(x), clf_target(T(x)) (KTGNN.py:432-434; `xt` = hidden activation h1 of T, whose
         last Linear is folded into the packed weights) with ONE halo exchange: the six narrow
         tables are interleaved column-wise in one allocation (row = [base | target | target-hat] x pad4(C) floats),
@@ -537,12 +553,16 @@ class PartitionedKTGNN:
         ld = ops.pad4(C)
         big = torch.empty(2 * p.n_local + p.n_halo, 3 * ld, dtype=torch.float32, device=self.device)
         views = [(big[p.n_local:, j * ld:(j + 1) * ld], big[:, j * ld:(j + 1) * ld]) for j in range(3)]   # (h_t2s, h_s2t)
-        m.clf_base.transform(x, self.mask_u8, sums=s_h, partner=m.clf_target, out=[views[0], views[1]])
-        if raw is not None:                                          # stage B of the fused linear -> narrow transform
-            ops.narrow_transform_finish(raw, self.mask_u8, s_t, pack_t, views[2])
+        if fuse:
+            if not m._classifier_stage_fused(x, self.mask_u8, s_h, views, arena):
+                return None                                          # outside the kernel's envelope: the caller takes the separate launches
         else:
-            xtp = _pad_cols4(xt)
-            ops.adaptedconv_transform(xtp, self.mask_u8, None, m._composed_target_pack(xtp.shape[1]), out=[views[2]], sums=s_t)
+            m.clf_base.transform(x, self.mask_u8, sums=s_h, partner=m.clf_target, out=[views[0], views[1]])
+            if raw is not None:                                      # stage B of the fused linear -> narrow transform
+                ops.narrow_transform_finish(raw, self.mask_u8, s_t, pack_t, views[2])
+            else:
+                xtp = _pad_cols4(xt)
+                ops.adaptedconv_transform(xtp, self.mask_u8, None, m._composed_target_pack(xtp.shape[1]), out=[views[2]], sums=s_t)
         self.halo.start(big)
         akey = (m.clf_base._versions(), m.clf_target._versions())
         if getattr(m, "_a3_key", None) != akey:                      # same cache as the single-GPU forward

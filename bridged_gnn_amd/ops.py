@@ -68,32 +68,37 @@ class DstCSR:
             self._hubs[key] = DstCSR._hub_tables_of(self.transposed()[0], self.num_nodes, threshold, segment)
         return self._hubs[key]
 
-    def tile_need(self, mask_u8, rows_per_tile=32):
+    def tile_need(self, mask_u8, rows_per_tile=32, table_mask_u8=None):
         """Per 32-row tile: which of a node's two transformed rows does the aggregation over THIS graph ever read?  bit 0 = h_s2t
         (gathered by target-domain destinations, KTGNN.py:293,:295), bit 1 = h_t2s (source-domain destinations, :292,:294); a
-        row's own table counts (the logit reads h_i).  -> int32 [ceil(N / 32)] for `adaptedconv_transform(tile_need=...)`, or
+        row's own table counts (the logit reads h_i).  -> int32 [ceil(rows / 32)] for `adaptedconv_transform(tile_need=...)`, or
         None when every tile needs both tables.  Built once per (graph, mask); with s -> t bridge edges only, no target node
-        feeds a source destination and the target half of h_t2s is never read."""
-        key = (mask_u8.data_ptr(), mask_u8._version, int(rows_per_tile))
+        feeds a source destination and the target half of h_t2s is never read.
+        `table_mask_u8` (a rank's graph: destinations = its own rows, tables = own rows followed by halo rows): the domain flags of
+        ALL table rows; the tiles then cover the extended tables and a halo row counts only where an edge reads it."""
+        key = (mask_u8.data_ptr(), mask_u8._version, int(rows_per_tile), None if table_mask_u8 is None else table_mask_u8.data_ptr())
         c = getattr(self, "_tile_need", None)
         if c is None or c[0] != key:
             E, N = self.num_edges, self.num_nodes
+            R = N if table_mask_u8 is None else int(table_mask_u8.shape[0])      # rows of the tables
             m = mask_u8[:N].bool()
             deg = (self.rowptr[1:N + 1] - self.rowptr[:N]).long()
             dst_s = torch.repeat_interleave(m, deg)                       # domain of every edge's destination (by-destination order)
             col = self.col[:E].long()
-            need_t2s, need_s2t = m.clone(), ~m
+            need_t2s = torch.zeros(R, dtype=torch.bool, device=m.device)
+            need_s2t = torch.zeros(R, dtype=torch.bool, device=m.device)
+            need_t2s[:N], need_s2t[:N] = m, ~m
             need_t2s[col[dst_s]] = True
             need_s2t[col[~dst_s]] = True
-            T = (N + rows_per_tile - 1) // rows_per_tile
-            pad = T * rows_per_tile - N
+            T = (R + rows_per_tile - 1) // rows_per_tile
+            pad = T * rows_per_tile - R
 
             def tiles(v):
                 v = torch.cat((v, v.new_zeros(pad))) if pad else v
                 return v.view(T, rows_per_tile).any(1)
             need = (tiles(need_s2t).to(torch.int32) | (tiles(need_t2s).to(torch.int32) << 1)).contiguous()
             full = bool((need == 3).all().item())                         # one-time sync, like the CSR build
-            self._tile_need = c = (key, None if full else need, mask_u8)  # (mask kept alive: the key holds its address)
+            self._tile_need = c = (key, None if full else need, mask_u8, table_mask_u8)  # (masks kept alive: the key holds their addresses)
         return c[1]
 
     def transposed(self):

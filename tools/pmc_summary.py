@@ -15,7 +15,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-KEEP = ("agg_wide_kernel", "agg_heads", "agg_kernel", "agg_bwd", "gram_", "bn_", "colstats", "transform_bwd", "transform_wreg_kernel", "transform_stream", "transform_gemm_kernel", "transform_skinny_kernel",
+KEEP = ("agg_wide", "cls_stage", "agg_heads", "agg_kernel", "agg_bwd", "gram_", "bn_", "colstats", "transform_bwd", "transform_wreg_kernel", "transform_stream", "transform_gemm_kernel", "transform_skinny_kernel",
         "domain_sums_kernel", "cosine_pass1", "knn_", "refine_kernel", "normalize_rows_kernel", "narrow_finish_kernel")
 
 
@@ -47,7 +47,7 @@ def main(src, dst):
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     for g in ("local", "uniform"):
         try:
-            fk = next(k for k in summary[f"fetch_{g}"] if k.startswith("agg_wide_kernel"))
+            fk = next(k for k in summary[f"fetch_{g}"] if k.startswith("agg_wide"))
             fetch = summary[f"fetch_{g}"][fk]["FETCH_SIZE"]["mean"]
             write = summary[f"write_{g}"][fk]["WRITE_SIZE"]["mean"]
         except (KeyError, StopIteration):
@@ -55,7 +55,7 @@ def main(src, dst):
         rec = {"kernel": f"{fk} hidden AdaptedConv aggregation, C4 {g} graph", "fetch_size_kb": fetch, "write_size_kb": write,
                "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
                "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount, MI355X_MICROARCH.md HBM section), WRITE_SIZE exact; KB = 1024 B",
-               "source": f"counters_fetch_{g}.csv + counters_write_{g}.csv (rocprofv3 --pmc, tools/profile_r02.sh)",
+               "source": f"counters_fetch_{g}.csv + counters_write_{g}.csv (rocprofv3 --pmc, tools/profile_r03.sh)",
                "workload": {"nodes": 1000000, "edges": 20000000, "hidden": 128, "graph": g}}
         tcc = summary.get(f"tcc_{g}", {}).get(fk)
         if tcc and "TCC_HIT_sum" in tcc:
