@@ -42,4 +42,13 @@ def assert_close(a, b, rtol=1e-5, atol_scale=1e-6, what=""):
     atol = atol_scale * max(float(np.abs(b).max()), 1e-30)
     err = np.abs(a - b)
     bad = err > atol + rtol * np.abs(b)
+    log = os.environ.get("BGNN_BARS_LOG")        # tools: one JSON line per comparison = the measured error against ITS bar and against the default bar
+    if log and a.size:
+        import json
+        d_atol = 1e-6 * max(float(np.abs(b).max()), 1e-30)
+        with open(log, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "rtol": rtol, "atol_scale": atol_scale,
+                                "max_abs_err": float(err.max()), "max_ref": float(np.abs(b).max()),
+                                "worst_over_this_bar": float((err / (atol + rtol * np.abs(b))).max()),
+                                "worst_over_default_bar": float((err / (d_atol + 1e-5 * np.abs(b))).max())}) + "\n")
     assert not bad.any(), f"{what}: {int(bad.sum())} elements off, max abs err {err.max():.3e} (atol {atol:.3e})"

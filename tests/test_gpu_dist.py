@@ -125,13 +125,13 @@ def _gloo_gpu_worker(rank, world, port, q):
             pk = PartitionedKTGNN(m, ei, mask, rank, world, DEV, cache_input_halo=cache, halo_mode=mode)
             xl = x[pk.owned_global].contiguous()
             out = pk.forward(xl)
-            ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out, ref))
+            ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-6) for a, b in zip(out, ref))
             if cache:                            # an in-place update of the features must re-fetch their halo
                 xl.mul_(0.5)
                 with torch.no_grad():
                     ref2 = m(Data(x=x * 0.5, edge_index=_t(ei), central_mask=_t(mask)))[:3]
                 out2 = pk.forward(xl)
-                ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out2, ref2))
+                ok = ok and all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-6) for a, b in zip(out2, ref2))
         q.put((rank, bool(ok), pk.plan.summary()))
     finally:
         dist.destroy_process_group()
@@ -256,7 +256,7 @@ def _nccl_world1_worker(port, q):
             xl = x[pk.owned_global].contiguous()
             with torch.no_grad():
                 out = pk.forward(xl)
-                res[f"eager_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(out, ref))
+                res[f"eager_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-6) for a, b in zip(out, ref))
                 # the bench's second phase: the forward INCLUDING its RCCL calls captured into a HIP graph and replayed
                 for _ in range(2):
                     pk.forward(xl)
@@ -267,7 +267,7 @@ def _nccl_world1_worker(port, q):
                 for _ in range(3):
                     gr.replay()
                 torch.cuda.synchronize()
-                res[f"replay_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-5) for a, b in zip(got, ref))
+                res[f"replay_cache{int(cache)}"] = all(torch.allclose(a, b[pk.owned_global], rtol=1e-5, atol=1e-6) for a, b in zip(got, ref))
         # the kNN bridge's collective on device buffers
         t = torch.randn(37, 128, device=DEV)
         res["all_gather_rows"] = bool(torch.equal(all_gather_rows(t, always=True), t))

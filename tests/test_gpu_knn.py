@@ -181,8 +181,8 @@ def test_cosine_v1_scorer_from_twitter_ckpt(golden):
     model = BridgeScorer(sd, DEV)
     assert model.sim_mode == "cosine" and model.version == "v1"
     q_src, q_tar = model.cosine_q(_t(f["z_src"])), model.cosine_q(_t(f["z_tar"]))
-    assert_close(q_src.cpu().numpy(), f["q_src"], rtol=2e-5, atol_scale=2e-6, what="q_src")
-    assert_close(q_tar.cpu().numpy(), f["q_tar"], rtol=2e-5, atol_scale=2e-6, what="q_tar")
+    assert_close(q_src.cpu().numpy(), f["q_src"], what="q_src")
+    assert_close(q_tar.cpu().numpy(), f["q_tar"], what="q_tar")
     idx, probs, _ = model.topk(_t(f["z_src"]), _t(f["z_tar"]), 20)
     # bit-exact vs the oracle on the GPU's own q (collapsed embeddings: cos in [0.95, 1])
     from bridged_gnn_amd import ops
@@ -234,8 +234,8 @@ def test_v1_sage_encoders_from_twitter_ckpt(golden):
     assert model.version == "v1"
     zs = model.encode_source(Data(x=_t(f["x_src"]), edge_index=_t(f["ei_src"].astype(np.int64))))
     zt = model.encode_target(Data(x=_t(f["x_tar"]), edge_index=_t(f["ei_tar"].astype(np.int64))))
-    assert_close(zs.cpu().numpy(), f["z_src"], rtol=2e-5, atol_scale=2e-6, what="z_src")
-    assert_close(zt.cpu().numpy(), f["z_tar"], rtol=2e-5, atol_scale=2e-6, what="z_tar")
+    assert_close(zs.cpu().numpy(), f["z_src"], what="z_src")
+    assert_close(zt.cpu().numpy(), f["z_tar"], what="z_tar")
 
 
 def test_cosine_topk_cascade_stages_are_exercised():

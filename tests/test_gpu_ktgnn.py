@@ -94,7 +94,7 @@ def test_adaptedconv_shapes_vs_c_oracle(din, D, n):
     hs2t, ht2s = OC.adaptedconv_transform(x, mask, prm)
     rowptr, col, _ = O.dst_csr(ei, mask)
     ref = OC.adaptedconv_aggregate(ht2s, hs2t, prm["a_f_t2s.weight"], prm["a_f_s2t.weight"], rowptr, col, mask)
-    assert_close(out.cpu().numpy(), ref, rtol=1e-5, atol_scale=2e-6, what=f"out din={din} D={D}")
+    assert_close(out.cpu().numpy(), ref, what=f"out din={din} D={D}")
 
 
 @pytest.mark.parametrize("din,D,n", [(128, 128, 5000), (64, 64, 4133), (100, 128, 2999), (128, 32, 3001), (96, 192, 1111),
@@ -112,8 +112,8 @@ def test_transform_w_stationary_kernel_shapes(din, D, n):
         h_t2s, h_s2t = conv.transform(_t(x), _as_u8(_t(mask)))
     prm = {k: v.cpu().numpy() for k, v in conv.state_dict().items()}
     hs2t, ht2s = OC.adaptedconv_transform(x, mask, prm)
-    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=2e-6, what=f"h_t2s din={din} D={D}")
-    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=2e-6, what=f"h_s2t din={din} D={D}")
+    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, what=f"h_t2s din={din} D={D}")
+    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, what=f"h_s2t din={din} D={D}")
 
 
 @pytest.mark.parametrize("din,dout,n,relu", [(128, 128, 4097, True), (64, 64, 1000, False), (100, 256, 333, True), (128, 192, 2500, True)])
@@ -131,7 +131,7 @@ def test_linear_relu_colsum(din, dout, n, relu):
     ref = x.astype(np.float64) @ W.astype(np.float64).T + b
     if relu:
         ref = np.maximum(ref, 0.0)
-    assert_close(out.cpu().numpy(), ref, rtol=1e-5, atol_scale=2e-6, what="linear")
+    assert_close(out.cpu().numpy(), ref, what="linear")
     got = sums.cpu().numpy()
     o64 = out.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(got[:dout], o64[mask].sum(0), rtol=1e-6, atol=1e-4)
@@ -202,8 +202,8 @@ def test_transform_fuzz_vs_c_oracle(seed):
         h_t2s, h_s2t = conv.transform(_t(x), _as_u8(_t(mask)))
     prm = {k: v.cpu().numpy() for k, v in conv.state_dict().items()}
     hs2t, ht2s = OC.adaptedconv_transform(x, mask, prm)
-    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=2e-6, what=f"h_t2s seed={seed} din={din} D={D} n={n}")
-    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=2e-6, what=f"h_s2t seed={seed} din={din} D={D} n={n}")
+    assert_close(h_t2s[:, :D].cpu().numpy(), ht2s, what=f"h_t2s seed={seed} din={din} D={D} n={n}")
+    assert_close(h_s2t[:, :D].cpu().numpy(), hs2t, what=f"h_s2t seed={seed} din={din} D={D} n={n}")
     assert float(h_t2s[:, D:].abs().max()) == 0.0 if h_t2s.shape[1] > D else True     # pad columns stay exactly zero
 
 
@@ -312,8 +312,8 @@ def test_fused_transformer_target_tables(hidden, C, n):
     finally:
         os.environ.pop("BGNN_FUSED_TARGET", None)
     assert ops.linear_narrow_supported(hidden, hidden, model._composed_target_pack(hidden)) == (hidden <= 128)   # 256: fallback
-    assert_close(a[0][:, 2 * ld:].cpu().numpy(), b[0][:, 2 * ld:].cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="h_t2s")
-    assert_close(a[1][:, 2 * ld:].cpu().numpy(), b[1][:, 2 * ld:].cpu().numpy(), rtol=1e-5, atol_scale=2e-6, what="h_s2t")
+    assert_close(a[0][:, 2 * ld:].cpu().numpy(), b[0][:, 2 * ld:].cpu().numpy(), what="h_t2s")
+    assert_close(a[1][:, 2 * ld:].cpu().numpy(), b[1][:, 2 * ld:].cpu().numpy(), what="h_s2t")
     assert_close(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=1e-6, atol_scale=1e-6, what="domain sums of h1")
     assert float((a[0][:, : 2 * ld] - 9.0).abs().max()) == 0.0          # neighbours' columns of the interleaved tables untouched
     if ld > C:
@@ -324,8 +324,8 @@ def test_fused_transformer_target_tables(hidden, C, n):
         model.clf_transformer.float()
     prm = {k: v.cpu().numpy() for k, v in model.clf_target.state_dict().items()}
     hs2t, ht2s = OC.adaptedconv_transform(xt.cpu().numpy(), mask.cpu().numpy().astype(bool), prm)
-    assert_close(a[0][:, 2 * ld: 2 * ld + C].cpu().numpy(), ht2s, rtol=1e-5, atol_scale=4e-6, what="h_t2s vs oracle")
-    assert_close(a[1][:, 2 * ld: 2 * ld + C].cpu().numpy(), hs2t, rtol=1e-5, atol_scale=4e-6, what="h_s2t vs oracle")
+    assert_close(a[0][:, 2 * ld: 2 * ld + C].cpu().numpy(), ht2s, what="h_t2s vs oracle")
+    assert_close(a[1][:, 2 * ld: 2 * ld + C].cpu().numpy(), hs2t, what="h_s2t vs oracle")
 
 
 @pytest.mark.parametrize("n,din", [(1, 4), (257, 36), (5000, 128), (100_003, 300), (70_000, 64)])
@@ -399,7 +399,7 @@ def test_root_weight_and_normalize_paths():
     ref, *_ = O.adaptedconv_forward(x, mask, e1, e2, prm)
     ref = ref + x @ prm["lin_r.weight"].T                                   # KTGNN.py:309-310
     ref = ref / np.maximum(np.linalg.norm(ref, axis=1, keepdims=True), 1e-12)   # :312-313
-    assert_close(out, ref, rtol=1e-5, atol_scale=2e-6, what="root_weight+normalize")
+    assert_close(out, ref, what="root_weight+normalize")
 
 
 def test_ktgnn_office_golden(golden):
@@ -516,7 +516,7 @@ def test_degree_skew_hub_rows():
     got = out.cpu().numpy()
     hubs = np.array([7, n - 3])
     rest = np.setdiff1d(np.arange(n), hubs)
-    assert_close(got[rest], ref[rest], rtol=1e-5, atol_scale=2e-6, what="non-hub rows")
+    assert_close(got[rest], ref[rest], rtol=1e-5, atol_scale=2e-6, what="non-hub rows")     # measured 1.3x the default bar (9.2e-6 abs): rows fed by node 11, whose 30k out-edges make the fp32 ORACLE sum them serially
     # The 50k / 20k-edge rows see logits up to |l| ~ 35, where ONE fp32 ulp of a logit (3.8e-6) already moves a softmax
     # weight by 4e-6 relative: the fp32 bar for those rows is conditioned on max|l| (the oracle accumulates in fp64).
     for r, H, a in ((7, hS, a1), (n - 3, hT, a2)):
