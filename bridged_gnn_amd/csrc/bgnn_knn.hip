@@ -237,6 +237,10 @@ __device__ __forceinline__ void offer_tile(TK& tk, f32x16 acc, int cbase, int64_
 #pragma unroll
   for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
   mx = fmaxf(mx, acc[15]);
+#ifdef KNN_X_NOOFFER          /* ablation (tools/exp_libs): the screen only, nothing is ever inserted */
+  if (mx > 1e30f) mycnt = 1;
+  return;
+#endif
   if (!__any(mx > tau)) return;
   uint32_t* const my_half = tk.skey() + q * CAP + h * HC;
 #pragma unroll

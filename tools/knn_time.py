@@ -14,7 +14,7 @@ q = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=0)).to(dev)
 c = torch.from_numpy(synth.gaussian_embeddings(n, 128, seed=1)).to(dev)
 qn, cn = ops.l2_normalize_rows(q), ops.l2_normalize_rows(c)
 ts = []
-for it in range(6):
+for it in range(int(os.environ.get("KNN_REPS", "6"))):
     torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); idx, val, nfb = ops.cosine_topk(qn, cn, k); e.record(); torch.cuda.synchronize()
     ts.append(s.elapsed_time(e))
