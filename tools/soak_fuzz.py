@@ -1,5 +1,5 @@
 """Soak of the seeded parity fuzzers (aggregation, transform, cosine kNN vs the C oracle) over seeds the test suite does
-not use: `python tools/soak_fuzz.py [first_seed [count]]` on a GPU box.  Round 1: seeds 100..259, 0 failures; round 2 (hub-row segments, lane-per-head kernels, kNN cascade): seeds 300..499, 0 failures; with the quad-cooperative exact re-score in the refine stage: seeds 500..699, 0 failures; after the scratch-clearing change (own zero-fill kernel): seeds 800..999, 0 failures."""
+not use: `python tools/soak_fuzz.py [first_seed [count]]` on a GPU box.  Round 1: seeds 100..259, 0 failures; round 2 (hub-row segments, lane-per-head kernels, kNN cascade): seeds 300..499, 0 failures; with the quad-cooperative exact re-score in the refine stage: seeds 500..699, 0 failures; after the scratch-clearing change (own zero-fill kernel): seeds 800..999, 0 failures; round 3 (stream / classifier-stage transform kernels, fast aggregation where the graph has no hub rows): seeds 1000..1199, 0 failures."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
