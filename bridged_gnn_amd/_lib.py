@@ -48,7 +48,7 @@ SIGNATURES = {
     "bgnn_adaptedconv_aggregate_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
                                                _P, _I64, _P, _P, _P, _INT, _P, _INT, _I64, _I32, _P, _P, _P]),
     "bgnn_adaptedconv_aggregate_bounded_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _F32,
-                                                       _P, _I64, _P, _P, _P, _INT, _P, _INT, _I64, _I32, _P, _P, _I64, _P]),
+                                                       _P, _I64, _P, _P, _P, _INT, _P, _INT, _I64, _I32, _P, _P, _I64, _I32, _P]),
     "bgnn_aggregate_hub_workspace_bytes": (C.c_size_t, [_I64, _I32, _I64]),
     "bgnn_adaptedconv_aggregate_hub_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _F32, _P, _I64, _P, _P, _INT, _P, _I32, _P,
                                                    _P, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, C.c_size_t, _P]),

@@ -69,6 +69,7 @@ struct AggParams {
   // agg_wide_fast_kernel only (filled by fast_plan): both tables inside ONE window of < 4 GB, addressed by 32-bit byte offsets
   const char* tbl_base;
   uint32_t tbl_bytes, off_t2s, off_s2t;
+  int32_t gather_hint; // 0 unknown, 1 neighbouring rows share neighbours (L2-resident gathers), 2 scattered (HBM-bound): resident blocks per CU
   uint32_t dead_off;   // row offset of a dead slot: lane base + dead_off is past the window and below 2^32, or 0 (row 0) when that does not fit
 };
 
@@ -1091,16 +1092,27 @@ static bool fast_plan(AggParams& p, int64_t table_rows) {
 template <int LF, bool ALPHA>
 int launch_wide_fast(const AggParams& p, hipStream_t st) {
   constexpr int RPB = 4 * (64 / LF);
-  static const int cap = [] {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 2048;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_fast_kernel<LF, ALPHA>, 256, 0) != hipSuccess || per_cu < 1) return 2048;
+  // resident blocks per CU: everything that fits (5 at 82 VGPRs) when the gathers live off the L2s -- more waves hide more L2 latency (C4:
+  // 0.938 / 0.972 / 1.062 ms at 5 / 4 / 3) --, three when the caller knows the graph has no neighbour reuse: the launch is then HBM-bound and
+  // fewer streams of random rows do better (uniform-random C4: 1.660 / 1.619 / 1.585 ms)
+  static const int per_cu_max = [] {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, agg_wide_fast_kernel<LF, ALPHA>, 256, 0) != hipSuccess || per_cu < 1) return 0;
     if (per_cu > 8) per_cu = 8;
     const char* e = getenv("BGNN_AGG_BLOCKS_PER_CU");
     if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
-    return per_cu * prop.multiProcessorCount / 8 * 8;
+    return per_cu;
   }();
+  static const int n_cu = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+  }();
+  static const bool forced = getenv("BGNN_AGG_BLOCKS_PER_CU") != nullptr;
+  int per_cu = per_cu_max;
+  if (p.gather_hint == 2 && !forced && per_cu > 3) per_cu = 3;
+  const int64_t cap = (per_cu_max > 0 && n_cu > 0) ? (int64_t)per_cu * n_cu / 8 * 8 : 2048;
   const int64_t ntiles = (p.row_end - p.row_begin + RPB - 1) / RPB;
   int64_t grid = ntiles < cap ? (ntiles + 7) / 8 * 8 : cap;
   if (grid < 8) grid = 8;
@@ -1300,7 +1312,7 @@ static int aggregate_impl(const float* h_t2s, const float* h_s2t, int64_t ldh,
                           float* out, int64_t ldo, float* alpha_opt,
                           const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                           float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
-                          double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, void* stream) {
+                          double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, int32_t gather_hint, void* stream) {
   if (colsum_opt && heads != 1) return BGNN_E_SHAPE;
   if (part == 1 && (park_begin < row_begin || park_begin > row_end)) return BGNN_E_SHAPE;
   if (part < 0 || part > 3 || (part != 0 && (!state_ms_opt || alpha_opt))) return BGNN_E_NULL;
@@ -1318,6 +1330,7 @@ static int aggregate_impl(const float* h_t2s, const float* h_s2t, int64_t ldh,
   AggParams p{h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope,
               out, ldo, alpha_opt, ep_scale_opt, ep_shift_opt, ep_relu, tile_queue_opt, colsum_opt, heads, state_ms_opt, part,
               park_begin, 4};
+  p.gather_hint = gather_hint;
   hipStream_t st = (hipStream_t)stream;
   if (tile_queue_opt) {
     hipError_t e = bgnn_zero_async(tile_queue_opt, 8 * sizeof(uint32_t), st);
@@ -1335,7 +1348,7 @@ extern "C" int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h
                                               float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
                                               double* colsum_opt, uint32_t* tile_queue_opt, void* stream) {
   return aggregate_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope, out, ldo, alpha_opt,
-                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, 0, stream);
+                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, 0, 0, stream);
 }
 
 extern "C" int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
@@ -1345,10 +1358,11 @@ extern "C" int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const 
                                                       float* out, int64_t ldo, float* alpha_opt,
                                                       const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                                       float* state_ms_opt, int part, int64_t park_begin, int32_t heads,
-                                                      double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, void* stream) {
-  if (table_rows < row_end) return BGNN_E_SHAPE;
+                                                      double* colsum_opt, uint32_t* tile_queue_opt, int64_t table_rows, int32_t gather_hint,
+                                                      void* stream) {
+  if (table_rows < row_end || gather_hint < 0 || gather_hint > 2) return BGNN_E_SHAPE;
   return aggregate_impl(h_t2s, h_s2t, ldh, a_t2s, a_s2t, rowptr, col, mask, row_begin, row_end, D, negative_slope, out, ldo, alpha_opt,
-                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, table_rows, stream);
+                        ep_scale_opt, ep_shift_opt, ep_relu, state_ms_opt, part, park_begin, heads, colsum_opt, tile_queue_opt, table_rows, gather_hint, stream);
 }
 
 extern "C" size_t bgnn_aggregate_hub_workspace_bytes(int64_t n_segments, int32_t heads, int64_t ldo) {

@@ -101,6 +101,27 @@ class DstCSR:
             self._tile_need = c = (key, None if full else need, mask_u8, table_mask_u8)  # (masks kept alive: the key holds their addresses)
         return c[1]
 
+    def gather_hint(self, window=1024, samples=64):
+        """1: neighbouring destination rows share neighbours (the aggregation's gathers live off the L2s), 2: they do not (HBM-bound
+        gathers) -- `bgnn_adaptedconv_aggregate_bounded_f32(gather_hint=...)`.  Measured once per graph: over `samples` evenly spaced
+        windows of `window` consecutive destination rows (about what one XCD has in flight), reuse = 1 - distinct neighbour ids / edges."""
+        if getattr(self, "_gather_hint", None) is None:
+            N, E = self.num_nodes, self.num_edges
+            hint = 1
+            if N > 4 * window and E > 0:
+                starts = torch.linspace(0, N - window, samples, device=self.rowptr.device).long()
+                rp = self.rowptr.long()
+                tot = dist = 0
+                b, e = rp[starts].tolist(), rp[starts + window].tolist()            # one-time sync, like tile_need / the CSR build
+                for lo, hi in zip(b, e):
+                    if hi > lo:
+                        tot += hi - lo
+                        dist += int(torch.unique(self.col[lo:hi]).numel())
+                if tot > 0 and 1.0 - dist / tot < 0.3:
+                    hint = 2
+            self._gather_hint = hint
+        return self._gather_hint
+
     def transposed(self):
         """By-SOURCE view of the same edges, built once per graph (training only): (t_rowptr [N+1], t_eid [E'] = position
         of the edge in the by-destination order, t_dst [E'] = its destination), int32.  The atomic-free aggregation
@@ -572,7 +593,8 @@ def adaptedconv_aggregate(h_t2s, h_s2t, a_t2s, a_s2t, csr, mask_u8, D, negative_
         L.ptr(mask_u8), int(row_begin), row_end, D, float(negative_slope), L.ptr_rows(out), out.stride(0) // heads, L.ptr(alpha),
         L.ptr(ep_scale), L.ptr(ep_shift), 2 if log_softmax else (1 if ep_relu else 0), L.ptr(state_ms), int(part),
         int(row_begin) if park_begin is None else int(park_begin), int(heads), L.ptr(colsum),
-        L.ptr(tq) if not (part == 2 and _P2_STATIC) else None, min(int(h_t2s.shape[0]), int(h_s2t.shape[0])), L.stream())
+        L.ptr(tq) if not (part == 2 and _P2_STATIC) else None, min(int(h_t2s.shape[0]), int(h_s2t.shape[0])),
+        csr.gather_hint() if (heads == 1 and D > 32 and part == 0) else 0, L.stream())
     L.check(rc, "bgnn_adaptedconv_aggregate_bounded_f32")
     return (out, alpha) if want_alpha else out
 

@@ -264,7 +264,9 @@ int bgnn_adaptedconv_aggregate_f32(const float* h_t2s, const float* h_s2t, int64
  * (heads = 1, part = 0, no alpha, D > 32) address neighbour rows by 32-bit offsets inside one window that holds both tables, when
  * that window is below 4 GB and table_rows <= 2^24 (agg_wide_fast_kernel: C4 hidden conv 1.06 -> see DESIGN 4.1); every other
  * shape runs exactly what bgnn_adaptedconv_aggregate_f32 runs.  Ids >= table_rows read outside the tables (undefined), as they
- * do there.  BGNN_AGG_FAST=0 in the environment keeps the general kernel. */
+ * do there.  gather_hint: 0 = unknown, 1 = neighbouring destination rows share neighbours (the gathers live off the L2s), 2 = no
+ * neighbour reuse (HBM-bound gathers): only chooses how many blocks of the fast kernel stay resident per CU (results unchanged;
+ * DstCSR.gather_hint() measures it once per graph).  BGNN_AGG_FAST=0 in the environment keeps the general kernel. */
 int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const float* h_s2t, int64_t ldh,
                                            const float* a_t2s, const float* a_s2t,
                                            const int32_t* rowptr, const int32_t* col, const uint8_t* mask,
@@ -272,7 +274,7 @@ int bgnn_adaptedconv_aggregate_bounded_f32(const float* h_t2s, const float* h_s2
                                            float* out, int64_t ldo, float* alpha_opt,
                                            const float* ep_scale_opt, const float* ep_shift_opt, int ep_relu,
                                            float* state_ms_opt, int part, int64_t park_begin, int32_t heads, double* colsum_opt,
-                                           uint32_t* tile_queue_opt, int64_t table_rows, void* stream);
+                                           uint32_t* tile_queue_opt, int64_t table_rows, int32_t gather_hint, void* stream);
 
 /* The same aggregation for graphs with HUB rows.  A destination row is walked by one lane group, so a row with hundreds of
  * in-edges (the 581 source nodes of the Twitter_Graph stand-in have ~750) is a chain of dependent gather steps that outlives
