@@ -129,3 +129,42 @@ def test_fast_pull_backward_equals_the_atomic_backward(D, n, deg, slope, seed):
     for name, a, b in (("dh_t2s", pull[0], d1), ("dh_s2t", pull[1], d2), ("da_t2s", pull[2], da1), ("da_s2t", pull[3], da2)):
         assert rel(a, b) < 2e-5, (name, D, n, rel(a, b))           # (the atomic sums are order-dependent in the last bits: the bar of the older pair test)
     assert (pull[0][:, D:] == 0).all() and (pull[1][:, D:] == 0).all()
+
+
+@pytest.mark.parametrize("n,feat,classes,s_only_bridges", [(3, 128, 2, False), (33, 128, 2, True), (257, 100, 3, True), (1025, 128, 4, False),
+                                                           (4099, 72, 2, True)])
+def test_round3_forward_kernels_at_edge_sizes_vs_c_oracle(n, feat, classes, s_only_bridges):
+    """The eval forward at hidden 128 -- i.e. through transform_stream_kernel (tile_need on when the graph has s -> t bridges only),
+    agg_wide_fast_kernel, cls_stage_kernel and the three-head walk -- on graphs of 3 ... 4099 nodes (fewer rows than one tile, one row
+    past a tile, fewer tiles than CUs), input widths 72 / 100 / 128, 2-4 classes, against the C oracle's full forward at the default bar."""
+    from bridged_gnn_amd import synth
+    from bridged_gnn_amd.data import Data
+    from bridged_gnn_amd.ktgnn import KTGNN_no_complement
+    rng = np.random.default_rng(n)
+    ns = max(n // 2, 1)
+    if s_only_bridges:                                     # [sources ; targets], within-domain edges + source -> target bridges only
+        src_w = rng.integers(0, ns, 3 * ns); dst_w = rng.integers(0, ns, 3 * ns)
+        tw_s = ns + rng.integers(0, n - ns, 3 * (n - ns)); tw_d = ns + rng.integers(0, n - ns, 3 * (n - ns))
+        br_s = rng.integers(0, ns, 5 * (n - ns)); br_d = ns + rng.integers(0, n - ns, 5 * (n - ns))
+        ei = np.stack([np.concatenate([src_w, tw_s, br_s]), np.concatenate([dst_w, tw_d, br_d])]).astype(np.int64)
+        mask = np.arange(n) < ns
+    else:
+        ei, mask = synth.random_multigraph(n, 6 * n, frac_src=0.5, n_isolated=min(2, n - 1), seed=n)
+    x = rng.standard_normal((n, feat)).astype(np.float32)
+    torch.manual_seed(n)
+    model = KTGNN_no_complement(feat, classes, 2, 128, root_weight=False, use_bn=True, dim_share=feat, need_complement=False)
+    g = torch.Generator().manual_seed(3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    model = model.to(DEV).eval()
+    data = Data(x=_t(x), edge_index=_t(ei), central_mask=_t(mask))
+    with torch.no_grad():
+        out = [t.cpu().numpy() for t in model(data)[:3]]
+        emb = model.get_emb(data).cpu().numpy()[:, :128]
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rowptr, col, _ = O.dst_csr(ei, mask)
+    rb, rt, rth, remb = OC.ktgnn_forward_eval(x, rowptr, col, mask, sd, return_emb=True)
+    for name, got, ref in (("hidden conv (BN+ReLU)", emb, remb), ("logp_base", out[0], rb), ("logp_target", out[1], rt), ("logp_target_hat", out[2], rth)):
+        assert_close(got, ref, what=f"{name} n={n} feat={feat}")
