@@ -25,6 +25,18 @@ from . import ops
 __all__ = ["Linear", "AdaptedConv", "KTGNN_no_complement"]
 
 
+
+def _plist(module):
+    """the module's parameters as a cached list: `module.parameters()` walks the module tree (named_modules / _named_members) on every
+    call -- 0.15 ms of host time per forward at ~60 calls.  Parameter OBJECTS are registered once (construction); moves and in-place
+    updates change `data_ptr()` / `_version`, which the callers key on."""
+    pl = module.__dict__.get("_bgnn_plist")
+    if pl is None:
+        pl = list(module.parameters())
+        module.__dict__["_bgnn_plist"] = pl
+    return pl
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b with the weight gradient dY^T x on the streaming Gram kernel (ops.gram): for [N ~ 1e6, <= 128]
     operands the library GEMM reduces over N with 32-row macro tiles (1.8 ms on C4 vs 0.3 ms)."""
@@ -476,7 +488,7 @@ class AdaptedConv(nn.Module):
                 "g_s2t": self.a_g_s2t.weight.detach(), "g_t2s": self.a_g_t2s.weight.detach()}
 
     def _versions(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in _plist(self))
 
     def packed(self, din_pad, partner=None):
         """cached packed weights (re-packed when any parameter changed in place or moved)."""
@@ -551,7 +563,7 @@ class AdaptedConv(nn.Module):
         mask_u8 = _as_u8(central_mask).contiguous()
         if csr is None:
             csr = self._csr_for(edge_index, N)
-        if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in _plist(self))):
             out = self._forward_autograd(x_src, central_mask.bool(), mask_u8, csr)
             if self.root_weight and x_r is not None:
                 out = out + self.lin_r(x_r.float())
@@ -657,7 +669,7 @@ class KTGNN_no_complement(nn.Module):
         sums = None
         for ind, conv in enumerate(self.convs):                                   # :418-430
             sums_in, sums = sums, None
-            if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters())):
+            if self.use_bn and not self.training and not (torch.is_grad_enabled() and any(p.requires_grad for p in _plist(conv))):
                 sc, sh = bn_eval_affine(self.bns[ind])
                 if arena is None:                      # every float64 accumulator of this forward from one zero fill
                     arena = ops.ZeroArena(x.device, (len(self.convs) + 3) * (2 * ops.pad4(max(x.shape[1], conv.out_channels)) + 2))
@@ -696,7 +708,7 @@ class KTGNN_no_complement(nn.Module):
     def _fold_transformer(self):
         """eval BatchNorm of clf_transformer folded into its first Linear (re-folded when a parameter / buffer changes)."""
         l0, bn, _, l3 = self.clf_transformer
-        key = tuple((p.data_ptr(), p._version) for p in self.clf_transformer.parameters()) + \
+        key = tuple((p.data_ptr(), p._version) for p in _plist(self.clf_transformer)) + \
             (bn.running_mean._version, bn.running_var._version)
         if getattr(self, "_tf_key", None) != key:
             s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
@@ -830,7 +842,7 @@ class KTGNN_no_complement(nn.Module):
             logits_target = self.clf_target(x, None, central_mask=central_mask, csr=csr)                  # :434
             # the folded / raw-kernel eval form has no autograd: with grad enabled (fine-tuning with frozen BN, input
             # attribution) the module itself runs -- eval-mode BatchNorm is autograd-safe
-            needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.clf_transformer.parameters()))
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in _plist(self.clf_transformer)))
             if self.training and torch.is_grad_enabled():
                 l0, bn, _, l3 = self.clf_transformer
                 xt = l3(bn_relu_dropout_train(l0(x), bn, True, 0.0))
