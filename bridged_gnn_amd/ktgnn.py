@@ -527,11 +527,14 @@ class AdaptedConv(nn.Module):
         return _TransformFn.apply(x, self.lin_s.weight, self.lin_s.bias, self.lin_t.weight, self.lin_t.bias,
                                   self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self, sums, mean_hook)
 
-    def _forward_autograd(self, x, mask, mask_u8, csr):
-        """Differentiable path: fused HIP transform + fused HIP aggregation, each a `torch.autograd.Function`."""
+    def _forward_autograd(self, x, mask, mask_u8, csr, sums=None):
+        """Differentiable path: fused HIP transform + fused HIP aggregation, each a `torch.autograd.Function`.
+        `sums`: the domain sums of x when x is static input data (no gradient flows through them)."""
         D = self.out_channels
+        if sums is not None and (x.requires_grad or sums.numel() != 2 * ops.pad4(x.shape[1]) + 2):
+            sums = None
         h_t2s, h_s2t = _TransformFn.apply(x, self.lin_s.weight, self.lin_s.bias, self.lin_t.weight, self.lin_t.bias,
-                                          self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self)
+                                          self.a_g_s2t.weight, self.a_g_t2s.weight, mask_u8, self, sums)
         out = _AggregateFn.apply(h_t2s, h_s2t, self.a_f_t2s.weight.reshape(-1), self.a_f_s2t.weight.reshape(-1),
                                  csr, mask_u8, D, self.negative_slope)
         return out[:, :D]
@@ -564,7 +567,7 @@ class AdaptedConv(nn.Module):
         if csr is None:
             csr = self._csr_for(edge_index, N)
         if torch.is_grad_enabled() and (x_src.requires_grad or any(p.requires_grad for p in _plist(self))):
-            out = self._forward_autograd(x_src, central_mask.bool(), mask_u8, csr)
+            out = self._forward_autograd(x_src, central_mask.bool(), mask_u8, csr, sums=sums)
             if self.root_weight and x_r is not None:
                 out = out + self.lin_r(x_r.float())
             if self.normalize:
@@ -679,6 +682,10 @@ class KTGNN_no_complement(nn.Module):
                     sums = arena.take(2 * ops.pad4(conv.out_channels) + 2)
                 x = conv(x, None, central_mask=central_mask, csr=csr, epilogue=(sc, sh, True), colsum=sums, sums=sums_in)
             else:
+                if (ind == 0 and sums_in is None and torch.is_grad_enabled() and not x.requires_grad and x.dtype == torch.float32
+                        and x.stride(1) == 1 and x.shape[1] % 4 == 0):
+                    # training on static input features: their domain sums are the memo the eval forward keeps (one stream over x less per step)
+                    sums_in = self._input_domain_sums(x, central_mask, ops.ZeroArena(x.device, 2 * x.shape[1] + 2) if self._input_sums_miss(x, central_mask) else None)
                 x = conv(x, None, central_mask=central_mask, csr=csr, sums=sums_in)
                 if self.use_bn and self.training and torch.is_grad_enabled():
                     x = bn_relu_dropout_train(x, self.bns[ind], True, self.dropout)
@@ -689,6 +696,13 @@ class KTGNN_no_complement(nn.Module):
                     x = F.dropout(x, p=self.dropout, training=self.training)
         self._arena = arena
         return (x, sums) if want_sums else x
+
+    def _input_sums_miss(self, x, central_mask):
+        """would `_input_domain_sums` have to stream x (no memo for this tensor version, or a capture in progress)?"""
+        if torch.cuda.is_current_stream_capturing() or not getattr(self, "cache_input_sums", True):
+            return True
+        c = getattr(self, "_xsum_cache", None)
+        return not (c is not None and c[0]() is x and c[1] == x._version and c[2]() is central_mask and c[3] == central_mask._version)
 
     def _input_domain_sums(self, x, central_mask, arena):
         """Per-domain column sums of the graph's INPUT features (KTGNN.py:275 of the first conv).  `data.x` is static data
