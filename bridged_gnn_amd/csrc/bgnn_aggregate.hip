@@ -809,7 +809,16 @@ __global__ __launch_bounds__(256) void agg_wide_fast_kernel(AggParams p) {
     const float inv = 1.f / (s + 1e-16f);   // PyG softmax denominator (KTGNN.py:299)
     if constexpr (ALPHA) {
       if (lg < U) {                          // the lane that wrote a raw logit normalises it (program order, no fence)
-        for (int32_t e2 = beg + lg; e2 < end; e2 += U) p.alpha[e2] = __expf(p.alpha[e2] - m) * inv;
+        // four of the lane's slots per trip: the reads of a trip are in flight together (one read-modify-write per trip was a chain
+        // of dependent global round trips per row: 1.25 -> see profiles/r03/README.md)
+        for (int32_t e2 = beg + lg; e2 < end; e2 += 4 * U) {
+          float a[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = e2 + j * U < end ? p.alpha[e2 + j * U] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (e2 + j * U < end) p.alpha[e2 + j * U] = __expf(a[j] - m) * inv;
+        }
       }
     }
     if (rvalid && f0 < p.ldo) {
