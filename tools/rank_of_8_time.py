@@ -38,7 +38,9 @@ class FakeHalo(D.HaloExchange):
 pk = D.PartitionedKTGNN(model, ei, mask, rank, world, dev, always_communicate=False,
                         cache_input_halo=os.environ.get("CACHE_HALO", "1") != "0")
 pk.halo = FakeHalo(pk.plan, dev, None)
-pk.world = 1                                            # no all-reduce
+pk.world = 1
+pk.always = True                                        # ... but the code path of world > 1 (two-pass classifier stage, one batched all-reduce):
+pk._all_reduce = lambda t: t                             # the all-reduce itself is the identity stand-in
 print("plan", pk.plan.summary(), "send rows", int(pk.halo.send_rows.numel()), flush=True)
 x = torch.randn(pk.plan.n_local, 128, device=dev)
 with torch.no_grad():
