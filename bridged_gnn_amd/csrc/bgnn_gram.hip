@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
 //   dpre = (S ? dc_0 (1 - gam_0^2) : 0,  S ? 0 : dc_1 (1 - gam_1^2))
 //   Gall[i] = [G_s2t[i,:D] | G_t2s[i,:D] | dpre_0 dpre_1 | +-1/n_dom | 0...]  (p = pad4(2D+3) columns);  side[i] = (c1, c2, 1, 0)
 // 32 lanes own a row (two rows per wave); element-wise indexing over D so that any D works.
-template <bool EX>
+template <bool EX, int MAXK>
 __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int din,
                                                                  const float* __restrict__ G_s2t, const float* __restrict__ G_t2s,
                                                                  int64_t ldg, int D, const uint8_t* __restrict__ mask,
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
   // l32 + 32k of its rows), reduced over the block in a fixed order and written as one partial [p][4] per block: Gall is
   // not streamed a second time by a side Gram.  Layout of a partial = the entries of ex = Gall^T side that are used.
   extern __shared__ float exs[];                 // EX: [8 row groups][p * 4]
-  constexpr int MAXK = 4;
+  // MAXK: 32-column chunks of a G row a lane owns (EX: D <= 32 * MAXK; the narrow convs take MAXK = 1 -- with 4 their launches issued three
+  // predicated-off copies of every per-column instruction and were VALU-bound at 0.22 ms for 0.5 GB)
   const int tid = threadIdx.x, l32 = tid & 31;
   const float gc0 = gconst[0], gc1 = gconst[1];
   // column 2D+2 of Gall: d(delta)/d(x_i) = +1/n_S on source rows, -1/n_T on target rows -- the input gradient's term
@@ -425,26 +426,60 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) eu1[k] = eb1[k] = eu2[k] = eb2[k] = 0.f;
   const int64_t rows_per_pass = (int64_t)gridDim.x * 8;             // 8 rows per block and pass
-  auto do_row = [&](int64_t r) {
-    float a0 = 0.f, a1 = 0.f, d0 = 0.f, d1 = 0.f;
-    for (int k = l32 * 4; k < din; k += 128) {                      // din % 4 == 0 (host)
-      const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + k);
-      const float4 u = *reinterpret_cast<const float4*>(gx + k), v = *reinterpret_cast<const float4*>(gx + din + k);
-      a0 = fmaf(xv.x, u.x, a0); a0 = fmaf(xv.y, u.y, a0); a0 = fmaf(xv.z, u.z, a0); a0 = fmaf(xv.w, u.w, a0);
-      a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
+  // A row in two halves so that the loads of R rows are in flight together: written as one body per row the compiler kept every row's
+  // loads behind the previous row's stores (load -> 2 us -> arithmetic -> store, one row at a time: the narrow convs' launches ran at
+  // 2 TB/s, 0.22 ms for the 0.5 GB of x they read).
+  constexpr int R = 4, XK = 1;                                     // rows in flight per 32-lane group; 128-column chunks of x held in registers (wider inputs: loads in the finishing half)
+  struct RowRegs { float4 xv[XK]; float g1v[MAXK], g2v[MAXK]; bool S; };
+  const bool x_in_regs = din <= 128 * XK;
+  auto load_row = [&](RowRegs& q, int64_t r) {
+    if (x_in_regs) {
+#pragma unroll
+      for (int c = 0; c < XK; ++c) {
+        const int k = l32 * 4 + 128 * c;
+        q.xv[c] = k < din ? *reinterpret_cast<const float4*>(x + r * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-    float* go = Gall + r * ld_gall;
-    float g1v[MAXK], g2v[MAXK];
     if constexpr (EX) {
 #pragma unroll
       for (int k = 0; k < MAXK; ++k) {
         const int c = l32 + 32 * k;
-        g1v[k] = g2v[k] = 0.f;
+        q.g1v[k] = c < D ? G_s2t[r * ldg + c] : 0.f;
+        q.g2v[k] = c < D ? G_t2s[r * ldg + c] : 0.f;
+      }
+    }
+    q.S = mask[r] != 0;
+  };
+  auto finish_row = [&](const RowRegs& q, int64_t r) {
+    float a0 = 0.f, a1 = 0.f, d0 = 0.f, d1 = 0.f;
+    if (x_in_regs) {
+#pragma unroll
+      for (int c = 0; c < XK; ++c) {
+        const int k = l32 * 4 + 128 * c;
+        if (k < din) {
+          const float4 xv = q.xv[c];
+          const float4 u = *reinterpret_cast<const float4*>(gx + k), v = *reinterpret_cast<const float4*>(gx + din + k);
+          a0 = fmaf(xv.x, u.x, a0); a0 = fmaf(xv.y, u.y, a0); a0 = fmaf(xv.z, u.z, a0); a0 = fmaf(xv.w, u.w, a0);
+          a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
+        }
+      }
+    } else {
+      for (int k = l32 * 4; k < din; k += 128) {                    // din % 4 == 0 (host)
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + k);
+        const float4 u = *reinterpret_cast<const float4*>(gx + k), v = *reinterpret_cast<const float4*>(gx + din + k);
+        a0 = fmaf(xv.x, u.x, a0); a0 = fmaf(xv.y, u.y, a0); a0 = fmaf(xv.z, u.z, a0); a0 = fmaf(xv.w, u.w, a0);
+        a1 = fmaf(xv.x, v.x, a1); a1 = fmaf(xv.y, v.y, a1); a1 = fmaf(xv.z, v.z, a1); a1 = fmaf(xv.w, v.w, a1);
+      }
+    }
+    float* go = Gall + r * ld_gall;
+    if constexpr (EX) {
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = l32 + 32 * k;
         if (c < D) {
-          g1v[k] = G_s2t[r * ldg + c]; g2v[k] = G_t2s[r * ldg + c];
-          d0 = fmaf(g1v[k], wd[c], d0);
-          d1 = fmaf(g2v[k], wd[2 * D + D + c], d1);
-          go[c] = g1v[k]; go[D + c] = g2v[k];
+          d0 = fmaf(q.g1v[k], wd[c], d0);
+          d1 = fmaf(q.g2v[k], wd[2 * D + D + c], d1);
+          go[c] = q.g1v[k]; go[D + c] = q.g2v[k];
         }
       }
     } else {
@@ -455,18 +490,31 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
         go[c] = g1; go[D + c] = g2;
       }
     }
-    a0 = bgnn::group_sum<32>(a0); a1 = bgnn::group_sum<32>(a1);
-    d0 = bgnn::group_sum<32>(d0); d1 = bgnn::group_sum<32>(d1);
-    const bool S = mask[r] != 0;
+    {
+      // the four row sums through ONE transposing butterfly (lane l ends with the total of value l & 3; quad broadcasts hand all four back
+      // to every lane): 6 selects + 6 DPP adds + a swizzle + 4 broadcasts instead of 4 x (5 adds incl. a swizzle each)
+      const bool b0 = l32 & 1, b1 = l32 & 2;
+      const float k0 = b0 ? a1 : a0, s0 = b0 ? a0 : a1, k1 = b0 ? d1 : d0, s1 = b0 ? d0 : d1;
+      const float u0 = k0 + bgnn::dpp_mov<0xB1>(s0), u1 = k1 + bgnn::dpp_mov<0xB1>(s1);     // lane parity: a0 | a1 and d0 | d1, summed over lane ^ 1
+      const float kk = b1 ? u1 : u0, ss = b1 ? u0 : u1;
+      float t = kk + bgnn::dpp_mov<0x4E>(ss);                                                   // lane & 3 = 0..3: a0, a1, d0, d1 over the quad
+      t += bgnn::dpp_mov<0x124>(t);                                                             // row_ror:4 (keeps lane & 3)
+      t += bgnn::dpp_mov<0x128>(t);                                                             // row_ror:8
+      t += bgnn::swz_xor16(t);
+      a0 = bgnn::dpp_mov<0x00>(t); a1 = bgnn::dpp_mov<0x55>(t); d0 = bgnn::dpp_mov<0xAA>(t); d1 = bgnn::dpp_mov<0xFF>(t);
+    }
+    const bool S = q.S;
     float g0 = 0.f, g1 = 0.f;
-    if (l32 == 0) { g0 = tanhf(a0 + gc0); g1 = tanhf(a1 + gc1); }
-    if constexpr (EX) {                          // the gate values reach the row's other lanes for the reductions below
-      g0 = __shfl(g0, threadIdx.x & 32); g1 = __shfl(g1, threadIdx.x & 32);
+    // the gate values as the FORWARD kernels form them (v_exp_f32 + v_rcp_f32, abs. error < 5e-7; bgnn_transform_params.h: tanh_fast).
+    // libm's tanhf on one lane per row was ~150 instructions per pair of rows: half of the launch on the narrow convs.
+    g0 = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * (a0 + gc0)) + 1.f);
+    g1 = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * (a1 + gc1)) + 1.f);
+    if constexpr (EX) {                          // (group_sum leaves the sums in every lane of the row: so are the gate values)
       const float c1 = S ? g0 : 0.f, c2 = S ? 0.f : g1;
 #pragma unroll
       for (int k = 0; k < MAXK; ++k) {
-        eu1[k] = fmaf(c1, g1v[k], eu1[k]); eb1[k] += g1v[k];
-        eu2[k] = fmaf(c2, g2v[k], eu2[k]); eb2[k] += g2v[k];
+        eu1[k] = fmaf(c1, q.g1v[k], eu1[k]); eb1[k] += q.g1v[k];
+        eu2[k] = fmaf(c2, q.g2v[k], eu2[k]); eb2[k] += q.g2v[k];
       }
     }
     if (l32 == 0) {
@@ -479,10 +527,19 @@ __global__ __launch_bounds__(256) void transform_bwd_prep_kernel(const float* __
       es0 += dp0; es1 += dp1;
     }
   };
-  // two rows per 32-lane group in flight (EX runs a smaller grid -- one partial per block -- so each wave carries more)
   int64_t r = (int64_t)blockIdx.x * 8 + (tid >> 5);
-  for (; r + rows_per_pass < N; r += 2 * rows_per_pass) { do_row(r); do_row(r + rows_per_pass); }
-  if (r < N) do_row(r);
+  for (; r + (R - 1) * rows_per_pass < N; r += R * rows_per_pass) {
+    RowRegs q[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) load_row(q[j], r + j * rows_per_pass);
+#pragma unroll
+    for (int j = 0; j < R; ++j) finish_row(q[j], r + j * rows_per_pass);
+  }
+  for (; r < N; r += rows_per_pass) {
+    RowRegs q;
+    load_row(q, r);
+    finish_row(q, r);
+  }
   if constexpr (EX) {
     const int P4 = p * 4, gi = tid >> 5;
     for (int t = tid; t < 8 * P4; t += 256) exs[t] = 0.f;
@@ -630,15 +687,15 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
   }
 }
 
-static int prep_blocks(int64_t N, bool ex) {
+static int prep_blocks(int64_t N, bool ex, int p = 1 << 20) {
   int64_t grid = (N + 7) / 8;
-  const int64_t cap = ex ? 2048 : 8192;          // EX: one [p][4] partial per block
+  const int64_t cap = (ex && p > 16) ? 2048 : 8192;          // EX: one [p][4] partial per block (narrow convs: 128-byte partials, the full grid)
   if (grid > cap) grid = cap;
   return grid < 1 ? 1 : (int)grid;
 }
 
 extern "C" size_t bgnn_transform_bwd_prep_workspace_bytes(int64_t N, int32_t p) {
-  return sizeof(float) * (size_t)prep_blocks(N > 0 ? N : 0, true) * (size_t)(p > 0 ? p : 0) * 4 + 256;
+  return sizeof(float) * (size_t)prep_blocks(N > 0 ? N : 0, true, p) * (size_t)(p > 0 ? p : 0) * 4 + 256;
 }
 
 extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t N, int32_t din, const float* G_s2t,
@@ -658,16 +715,21 @@ extern "C" int bgnn_transform_bwd_prep_f32(const float* x, int64_t ldx, int64_t 
     if (ex_opt && bgnn_zero_async(ex_opt, sizeof(float) * 4 * (size_t)p, st) != hipSuccess) return (int)hipErrorInvalidValue;
     return 0;
   }
-  const int grid = prep_blocks(N, ex_opt != nullptr);
+  const int grid = prep_blocks(N, ex_opt != nullptr, p);
   if (ex_opt) {
-    hipLaunchKernelGGL(transform_bwd_prep_kernel<true>, dim3((unsigned)grid), dim3(256), sizeof(float) * 8 * 4 * (size_t)p, st, x,
-                       ldx, N, din, G_s2t, G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side,
-                       (float*)ws_opt);
+    if (D <= 32)
+      hipLaunchKernelGGL((transform_bwd_prep_kernel<true, 1>), dim3((unsigned)grid), dim3(256), sizeof(float) * 8 * 4 * (size_t)p, st, x,
+                         ldx, N, din, G_s2t, G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side,
+                         (float*)ws_opt);
+    else
+      hipLaunchKernelGGL((transform_bwd_prep_kernel<true, 4>), dim3((unsigned)grid), dim3(256), sizeof(float) * 8 * 4 * (size_t)p, st, x,
+                         ldx, N, din, G_s2t, G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side,
+                         (float*)ws_opt);
     BGNN_LAUNCH_CHECK();
     const int64_t pq = (int64_t)p * 4;
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((pq + 63) / 64)), dim3(1024), 0, st, (const float*)ws_opt, grid, pq, ex_opt);
   } else {
-    hipLaunchKernelGGL(transform_bwd_prep_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, x, ldx, N, din, G_s2t,
+    hipLaunchKernelGGL((transform_bwd_prep_kernel<false, 4>), dim3((unsigned)grid), dim3(256), 0, st, x, ldx, N, din, G_s2t,
                        G_t2s, ldg, D, mask, gx, gconst, wd, counts, Gall, p, ld_gall, side_opt, ld_side, (float*)nullptr);
   }
   BGNN_LAUNCH_CHECK();
