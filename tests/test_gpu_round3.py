@@ -168,3 +168,19 @@ def test_round3_forward_kernels_at_edge_sizes_vs_c_oracle(n, feat, classes, s_on
     rb, rt, rth, remb = OC.ktgnn_forward_eval(x, rowptr, col, mask, sd, return_emb=True)
     for name, got, ref in (("hidden conv (BN+ReLU)", emb, remb), ("logp_base", out[0], rb), ("logp_target", out[1], rt), ("logp_target_hat", out[2], rth)):
         assert_close(got, ref, what=f"{name} n={n} feat={feat}")
+
+
+@pytest.mark.parametrize("din,dout,n,relu", [(8, 128, 4097, False), (4, 64, 333, True), (12, 128, 1000, False), (16, 256, 777, True), (8, 128, 1, False)])
+def test_linear_with_a_skinny_reduction(din, dout, n, relu):
+    """bgnn_linear_f32 at Din <= 16 (the input gradient Gall . Wcat of a narrow conv's transform backward, K = 8): against fp64 at the default
+    bar, row-strided input view included.  (A VALU kernel for this shape measured 0.20 ms against the W-stationary MFMA kernel's 0.13: not kept.)"""
+    from bridged_gnn_amd import ops
+    rng = np.random.default_rng(din * 1000 + dout + n)
+    xb = _t(rng.standard_normal((n, din + 4)).astype(np.float32))
+    x = xb[:, :din]                                                   # row stride din + 4
+    W = _t((rng.standard_normal((dout, din)) * 0.3).astype(np.float32))
+    b = _t(rng.standard_normal(dout).astype(np.float32))
+    got = ops.linear(x, W, b, relu=relu).cpu().numpy()
+    ref = x.double().cpu().numpy() @ W.double().cpu().numpy().T + b.double().cpu().numpy()
+    ref = np.maximum(ref, 0) if relu else ref
+    assert_close(got, ref, what=f"linear din={din} dout={dout} n={n}")
