@@ -29,12 +29,31 @@ __all__ = ["Linear", "AdaptedConv", "KTGNN_no_complement"]
 def _plist(module):
     """the module's parameters as a cached list: `module.parameters()` walks the module tree (named_modules / _named_members) on every
     call -- 0.15 ms of host time per forward at ~60 calls.  Parameter OBJECTS are registered once (construction); moves and in-place
-    updates change `data_ptr()` / `_version`, which the callers key on."""
+    updates change `data_ptr()` / `_version`, which the callers key on.  Everything that may REPLACE parameter objects drops the list:
+    `Module._apply` (`.to()` / `.float()` under `torch.__future__.set_overwrite_module_params_on_conversion`), `load_state_dict(assign=True)`
+    and `_drop_param_caches()`; code that assigns a new `nn.Parameter` to a submodule by hand calls `_forget_plists(model)`."""
     pl = module.__dict__.get("_bgnn_plist")
     if pl is None:
         pl = list(module.parameters())
         module.__dict__["_bgnn_plist"] = pl
     return pl
+
+
+def _forget_plists(root):
+    for m in root.modules():
+        m.__dict__.pop("_bgnn_plist", None)
+
+
+class _PlistHooks:
+    """mixin for the modules whose forward keys caches on `_plist`"""
+
+    def _apply(self, fn, *a, **k):
+        _forget_plists(self)
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        _forget_plists(self)
+        return super().load_state_dict(*a, **k)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -443,7 +462,7 @@ class _TransformPairFn(torch.autograd.Function):
         return (dX, None, None, None, None, *grads)
 
 
-class AdaptedConv(nn.Module):
+class AdaptedConv(_PlistHooks, nn.Module):
     """Reference `AdaptedConv(MessagePassing)` -- models/KTGNN.py:218-328.
 
     forward(x, edge_index, edge_index1, edge_index2, central_mask, size=None) -> [N, out_channels]
@@ -603,7 +622,7 @@ class AdaptedConv(nn.Module):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
 
 
-class KTGNN_no_complement(nn.Module):
+class KTGNN_no_complement(_PlistHooks, nn.Module):
     """Reference `KTGNN_no_complement` -- models/KTGNN.py:330-465 (need_complement=False only; every
     reference call site passes False: main_graph_knowledge_transfer.py:179,:332-333)."""
 
@@ -928,6 +947,7 @@ class KTGNN_no_complement(nn.Module):
         self._a3_key = None
         for bn in list(self.bns) + [self.clf_transformer[1]]:      # eval-mode scale / shift (bn_eval_affine)
             bn._bgnn_affine = None
+        _forget_plists(self)
 
     def invalidate_input_cache(self):
         """forget the memoised per-domain sums of `data.x` (`_input_domain_sums`).  The cache is keyed by tensor identity and
