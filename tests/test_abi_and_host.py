@@ -84,3 +84,58 @@ def test_synthetic_generators_are_deterministic():
     x, ei, y, m = synth.sync_rd_intra(n=400, feat=8, deg=4, k_cross=3, seed=1)
     same = (y[ei[0]] == y[ei[1]])[: 400 * 4]
     assert 0.6 < same.mean() < 0.8                                      # ~70 % homophily on intra edges
+
+
+def _csr_cpu(ei, n_dst):
+    """by-destination CSR of an edge list on CPU tensors (host logic only: what bgnn_build_dst_csr returns, without self-loop rewriting)"""
+    import numpy as np
+    import torch
+    from bridged_gnn_amd.ops import DstCSR
+    order = np.argsort(ei[1], kind="stable")
+    col = ei[0][order].astype(np.int32)
+    rowptr = np.zeros(n_dst + 1, dtype=np.int32)
+    np.add.at(rowptr, ei[1] + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return DstCSR(torch.from_numpy(rowptr), torch.from_numpy(col), None, col.shape[0], n_dst)
+
+
+def test_tile_need_over_own_and_halo_rows_matches_brute_force():
+    """`DstCSR.tile_need(mask, table_mask_u8=...)` (a rank's graph: destinations = own rows, tables = own rows followed by halo rows): bit 0 / 1 of
+    a 32-row tile = some destination of the target / source domain reads one of its rows from h_s2t / h_t2s, an own row's own table included."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(0)
+    n_dst, n_halo, E = 333, 150, 2500
+    R = n_dst + n_halo
+    ei = np.stack([rng.integers(0, R, E), rng.integers(0, n_dst, E)])
+    ei = ei[:, ~((ei[0] >= n_dst + 100))]                       # the last 50 halo rows are referenced by nobody
+    mask = rng.random(n_dst) < 0.4
+    tmask = np.concatenate([mask, rng.random(n_halo) < 0.5])
+    csr = _csr_cpu(ei, n_dst)
+    need = csr.tile_need(torch.from_numpy(mask).to(torch.uint8), table_mask_u8=torch.from_numpy(tmask).to(torch.uint8))
+    assert need is not None and need.shape[0] == (R + 31) // 32
+    want = np.zeros((R + 31) // 32, dtype=np.int32)
+    for i in range(n_dst):
+        want[i // 32] |= 2 if mask[i] else 1                    # the row's own table (the logit reads h_i)
+    for j, i in ei.T:
+        want[j // 32] |= 2 if mask[i] else 1                    # source-domain destinations gather from h_t2s (bit 1), targets from h_s2t (bit 0)
+    assert np.array_equal(need.numpy(), want)
+    assert (need.numpy()[-1] == 0)                              # nobody reads the unreferenced halo tail
+    # square graph, every row read from both tables -> None
+    full = np.stack([np.repeat(np.arange(64), 2), np.tile(np.array([0, 40]), 64)])
+    csr2 = _csr_cpu(full, 64)
+    m2 = np.zeros(64, dtype=bool); m2[:32] = True
+    assert csr2.tile_need(torch.from_numpy(m2).to(torch.uint8)) is None
+
+
+def test_gather_hint_separates_clustered_from_scattered_graphs():
+    """`DstCSR.gather_hint()`: 1 when neighbouring destination rows share neighbours (bridged / kNN graphs), 2 when they do not."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    n, deg = 200_000, 8
+    dst = np.repeat(np.arange(n), deg)
+    clustered = np.stack([(dst // 512) * 512 + rng.integers(0, 512, n * deg), dst])          # neighbours from the row's own block of 512
+    scattered = np.stack([rng.integers(0, n, n * deg), dst])
+    assert _csr_cpu(clustered, n).gather_hint() == 1
+    assert _csr_cpu(scattered, n).gather_hint() == 2
+    assert _csr_cpu(np.stack([rng.integers(0, 100, 800), np.repeat(np.arange(100), 8)]), 100).gather_hint() == 1      # too small to matter: default
