@@ -77,6 +77,28 @@ def test_fast_wide_aggregation_is_bit_identical_to_the_general_kernel(D, n, deg,
     assert (out[:, D:] == 0).all()
 
 
+def test_fast_wide_aggregation_with_a_window_above_2gb():
+    """Tables 2.5 GB apart: the window's byte count no longer fits a signed 32-bit integer (the buffer descriptor's num_records is unsigned) --
+    still the fast kernel, still the same bits as with adjacent tables."""
+    from bridged_gnn_amd import ops, synth
+    n, D = 3000, 128
+    rng = np.random.default_rng(6)
+    ei, mask = synth.random_multigraph(n, 7 * n, frac_src=0.4, n_isolated=2, seed=12)
+    csr = ops.build_dst_csr(_t(ei), n)
+    gap = (5 << 29) // 4                                   # 2.5 GB in floats
+    big = torch.empty(gap + n * D, dtype=torch.float32, device=DEV)
+    tS, tT = big[:n * D].view(n, D), big[gap:].view(n, D)
+    tS.copy_(_t(rng.standard_normal((n, D)).astype(np.float32))); tT.copy_(_t(rng.standard_normal((n, D)).astype(np.float32)))
+    a1, a2 = _t((rng.standard_normal(D) * 0.3).astype(np.float32)), _t((rng.standard_normal(D) * 0.3).astype(np.float32))
+    m8 = _t(mask).to(torch.uint8)
+    assert (1 << 31) < tT.data_ptr() - tS.data_ptr() + n * D * 4 < (1 << 32)
+    wide = ops.adaptedconv_aggregate(tS, tT, a1, a2, csr, m8, D, 0.1)
+    swapped = ops.adaptedconv_aggregate(tT, tS, a2, a1, csr, (1 - m8).contiguous(), D, 0.1)      # the other table on top: same function of the graph with domains swapped
+    both = torch.stack([tS, tT])
+    near = ops.adaptedconv_aggregate(both[0], both[1], a1, a2, csr, m8, D, 0.1)
+    assert torch.equal(wide, near) and torch.equal(swapped, near)
+
+
 def test_fast_wide_aggregation_falls_back_when_the_tables_are_4gb_apart():
     """Two tables whose window exceeds 32 bits of byte offsets take the general kernel: same result, no fault."""
     from bridged_gnn_amd import ops, synth
